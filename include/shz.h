@@ -1,0 +1,182 @@
+/*
+ * shz.h -- C ABI of libshz.so, the MI355X (gfx950) fingerprint / match hot path.
+ *
+ * The reference (CarlosArturoMe/shazam) is pure Python and has no FFI of its own
+ * (SURVEY.md 8b); this header is the boundary a maintainer binds with ctypes to put
+ * the HIP path behind the reference's own functions.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every function returns an int32 status: SHZ_OK or a negative SHZ_E_* code;
+ *     shz_last_error(ctx) gives a message owned by the ctx (valid until the next call).
+ *   - shz_ctx is one (device, stream); NOT thread-safe per ctx, independent ctxs are.
+ *   - the caller allocates every output buffer and passes its capacity; on overflow the
+ *     call returns SHZ_E_CAPACITY with the required count in *count (two-call idiom).
+ *   - pointers are host pointers unless the matching SHZ_*_DEVICE flag is set, in which
+ *     case they are device pointers obtained from shz_dev_alloc on the same ctx.
+ *   - the library never keeps a caller pointer past return; no exception crosses the ABI.
+ */
+#ifndef SHZ_H
+#define SHZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHZ_OK 0
+#define SHZ_E_INVALID (-1)   /* bad argument                                   */
+#define SHZ_E_HIP (-2)       /* a HIP runtime call failed                      */
+#define SHZ_E_CAPACITY (-3)  /* output buffer too small; *count = required     */
+#define SHZ_E_NOMEM (-4)     /* device or host allocation failed               */
+#define SHZ_E_UNSUPPORTED (-5)/* parameter combination the HIP path does not implement */
+#define SHZ_E_RCCL (-6)      /* RCCL missing or a collective failed            */
+#define SHZ_E_STATE (-7)     /* object used in the wrong state                 */
+
+#define SHZ_PCM_DEVICE 1u    /* pcm pointer is device memory                   */
+#define SHZ_OUT_DEVICE 2u    /* output pointers are device memory              */
+#define SHZ_IN_DEVICE 4u     /* generic: input arrays are device memory        */
+
+/* constants of the algorithm: __init__.py:41-51 == recognizer.py:21-38 */
+#define SHZ_NFFT 4096
+#define SHZ_HOP 2048
+#define SHZ_NBINS 2049
+#define SHZ_PEAK_RADIUS 10
+#define SHZ_MAX_DT 200
+#define SHZ_DEFAULT_FS 44100
+
+typedef struct shz_ctx shz_ctx;
+typedef struct shz_table shz_table;
+typedef struct shz_comm shz_comm;
+
+/* ---- context, memory, timing ------------------------------------------------------ */
+int32_t shz_ctx_create(int32_t device_id, shz_ctx** out);
+int32_t shz_ctx_destroy(shz_ctx* ctx);
+const char* shz_last_error(shz_ctx* ctx);
+const char* shz_version(void);
+/* name: >=128 bytes; any out pointer may be NULL */
+int32_t shz_device_info(shz_ctx* ctx, char* name, uint64_t name_cap, uint64_t* hbm_bytes,
+                        int32_t* compute_units, int32_t* clock_khz);
+int32_t shz_dev_alloc(shz_ctx* ctx, uint64_t bytes, void** dptr);
+int32_t shz_dev_free(shz_ctx* ctx, void* dptr);
+int32_t shz_copy_h2d(shz_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int32_t shz_copy_d2h(shz_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+int32_t shz_sync(shz_ctx* ctx);
+/* cap on the internal scratch arena (dB spectrogram, masks, sort buffers); batches are
+ * split into sub-batches that fit.  0 = default (1/4 of HBM). */
+int32_t shz_set_workspace_limit(shz_ctx* ctx, uint64_t bytes);
+/* hipEvent timers on the ctx stream (replaces the time() deltas at recognizer.py:214-220,
+ * 282-284, 388-390).  slot in [0,16). */
+int32_t shz_timer_start(shz_ctx* ctx, int32_t slot);
+int32_t shz_timer_stop(shz_ctx* ctx, int32_t slot, float* elapsed_ms);
+/* per-kernel accumulated device time of the last profiled call (see shz_set_profiling).
+ * which: 0 stft_psd_db, 1 peak_pick, 2 peak_expand(+scan), 3 pair_hash(+scan) */
+int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled);
+int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t* launches);
+
+/* ---- synthetic PCM (bench / tests input; numpy twin: oracle/synth.py) ------------------ */
+/* clips [clip0, clip0+n_clips) x n_samples int16, clip-major, written to DEVICE memory.
+ * tone_amp = 0 -> white noise uniform in [-noise_amp, noise_amp). */
+int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
+                      int32_t tone_amp, int32_t noise_amp, uint64_t start_sample, int16_t* dev_out);
+
+/* ---- extraction --------------------------------------------------------------------- */
+/* Frames mlab produces for n_samples (mlab.specgram via __init__.py:232-237). */
+uint32_t shz_frame_count(uint64_t n_samples);
+
+/* Stage parity/debug: dB spectrogram of a batch, replaces
+ *   mlab.specgram(x, NFFT=4096, Fs, window_hanning, noverlap=2048)[0] + 10*log10
+ *   (__init__.py:232-241).  clip_off: n_clips+1 sample offsets into pcm (host memory).
+ * out_db (HOST): per clip a float64 [2049, F_c] freq-major block (the reference's layout),
+ * blocks concatenated in clip order; cap_doubles = capacity of out_db in doubles. */
+int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
+                    uint32_t fs, uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* count);
+
+/* Constellation peaks of a batch: replaces get_2D_peaks(10*log10(specgram)) +
+ * the stable time sort at generate_hashes (__init__.py:116-177, 194-195).
+ * Outputs (host unless SHZ_OUT_DEVICE): peak_f/peak_t in (clip, time asc, freq asc)
+ * order, peak_off[n_clips+1] CSR offsets. */
+int32_t shz_peaks(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
+                  uint32_t fs, double amp_min, uint32_t flags,
+                  uint16_t* peak_f, uint32_t* peak_t, uint64_t* peak_off, uint64_t cap, uint64_t* count);
+
+/* get_2D_peaks(arr2D, amp_min) on a caller-supplied 2-D float64 array (__init__.py:116-177):
+ * arr2d is HOST, C-contiguous [n_rows(freq), n_cols(time)]; outputs in np.where row-major
+ * order (freq asc, time asc) like the reference's return value. */
+int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t n_rows, uint32_t n_cols,
+                          double amp_min, uint32_t* out_f, uint32_t* out_t, uint64_t cap, uint64_t* count);
+
+/* generate_hashes(peaks, fan_value) in packed form (__init__.py:179-210): peaks must be in
+ * (time asc, freq asc) order per clip (peak_off CSR, host).  key32 = f1<<20 | f2<<8 | dt. */
+int32_t shz_pair_hash(shz_ctx* ctx, const uint16_t* peak_f, const uint32_t* peak_t, const uint64_t* peak_off,
+                      uint32_t n_clips, uint32_t fan_value,
+                      uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count);
+
+/* fingerprint() for a batch of channels (__init__.py:212-245): PCM -> (key32, t1) in the
+ * reference's generation order, hash_off[n_clips+1] CSR offsets (always HOST).
+ * key32/t1 are host unless SHZ_OUT_DEVICE. */
+int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
+                              uint32_t fs, double amp_min, uint32_t fan_value, uint32_t flags,
+                              uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count);
+
+/* sha1(f"{f1}|{f2}|{dt}")[:10 bytes] per key (__init__.py:207-208; BINARY(10) at
+ * mysql_database.py:48).  key32: host or device (SHZ_IN_DEVICE); out10: host [n][10]. */
+int32_t shz_sha1_prefix(shz_ctx* ctx, const uint32_t* key32, uint64_t n, uint32_t flags, uint8_t* out10);
+
+/* ---- fingerprint table (replaces the MySQL fingerprints table, mysql_database.py:46-68) - */
+int32_t shz_table_create(shz_ctx* ctx, shz_table** out);
+int32_t shz_table_destroy(shz_table* t);
+/* INSERT IGNORE of rows (hash, song_id, offset) (mysql_database.py:62-68, 167-181);
+ * rows are staged; duplicates on (song_id, offset, hash) are dropped at finalize. */
+int32_t shz_table_insert(shz_table* t, const uint32_t* key32, const uint32_t* sid, const uint32_t* off,
+                         uint64_t n, uint32_t flags);
+/* same, one song per clip: song id of clip c = sid0 + c, rows from a CSR (key32, t1, hash_off) */
+int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, const uint32_t* t1, const uint64_t* hash_off,
+                               uint32_t n_clips, uint32_t sid0, uint32_t flags);
+/* sort staged+existing rows by (key, sid, off), drop duplicates, build the bucket index */
+int32_t shz_table_finalize(shz_table* t);
+int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged);
+/* sorted rows to host (dump / parity): arrays of cap rows */
+int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap, uint64_t* count);
+/* SELECT hash, song_id, offset WHERE hash IN (keys) (SELECT_MULTIPLE, mysql_database.py:82-86;
+ * recognizer.py:252-259): rows of every listed key, grouped in the order the keys are given,
+ * inside a key ordered by (song_id, offset).  keys: host; outputs: host arrays of cap rows. */
+int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t n_keys,
+                         uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap, uint64_t* count);
+/* distinct (hash, offset) rows of one song = songs.total_hashes candidates (__init__.py:381) */
+int32_t shz_table_song_rows(shz_table* t, uint32_t sid, uint64_t* n_rows);
+
+/* ---- match + align (replaces return_matches/align_matches, recognizer.py:222-338) ------- */
+/* Queries are CSR: query q owns (key32, q_off) pairs [query_off[q], query_off[q+1]); duplicate
+ * (key, q_off) pairs inside a query are collapsed (set semantics, recognizer.py:378-382).
+ * Outputs (host), per query up to topn results ranked like align_matches:
+ *   out_sid/out_delta/out_aligned [n_queries*topn]  (sid, db_off - q_off of the winning bin, its count)
+ *   out_dedup  [n_queries*topn]  dedup_hashes[sid] (DB rows matched, once per row, recognizer.py:261-264)
+ *   out_nres   [n_queries]       results valid for q
+ *   out_nhash  [n_queries]       len(set(hashes)) = queried_hashes (recognizer.py:389)
+ *   out_npairs [n_queries]       len(matches)
+ */
+int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                        const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
+                        uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
+                        uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs);
+/* rows streamed / pairs voted by the last shz_match_batch (for HBM accounting) */
+int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, uint64_t* distinct_keys);
+
+/* ---- multi-GPU database build (new) ---------------------------------------- */
+/* RCCL communicator, one rank per GPU.  id: 128-byte ncclUniqueId made by rank 0 and shipped
+ * to the other ranks by the host (torch.distributed / any store). */
+int32_t shz_comm_unique_id(uint8_t id_out[128]);
+int32_t shz_comm_create(shz_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t nranks, shz_comm** out);
+int32_t shz_comm_destroy(shz_comm* c);
+/* all-gather every rank's STAGED rows over RCCL/xGMI, then finalize: afterwards every rank
+ * holds the same node-global table.  bytes_recv: payload bytes this rank received. */
+int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv);
+int32_t shz_comm_barrier(shz_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHZ_H */

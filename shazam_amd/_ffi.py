@@ -1,0 +1,428 @@
+"""ctypes binding of libshz.so (include/shz.h).  numpy + ctypes only -- no torch, no CPU fallback:
+if the HIP library is missing or a call fails this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshz.so")
+
+OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
+PCM_DEVICE, OUT_DEVICE, IN_DEVICE = 1, 2, 4
+NFFT, HOP, NBINS = 4096, 2048, 2049
+
+u8p, u16p, u32p, i32p, u64p, i16p, f64p = (C.POINTER(t) for t in (
+    C.c_uint8, C.c_uint16, C.c_uint32, C.c_int32, C.c_uint64, C.c_int16, C.c_double))
+vp = C.c_void_p
+
+# name -> (restype, argtypes); the loader test checks every symbol in include/shz.h is exported
+SIGNATURES = {
+    "shz_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(vp)]),
+    "shz_ctx_destroy": (C.c_int32, [vp]),
+    "shz_last_error": (C.c_char_p, [vp]),
+    "shz_version": (C.c_char_p, []),
+    "shz_device_info": (C.c_int32, [vp, C.c_char_p, C.c_uint64, u64p, i32p, i32p]),
+    "shz_dev_alloc": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),
+    "shz_dev_free": (C.c_int32, [vp, vp]),
+    "shz_copy_h2d": (C.c_int32, [vp, vp, vp, C.c_uint64]),
+    "shz_copy_d2h": (C.c_int32, [vp, vp, vp, C.c_uint64]),
+    "shz_sync": (C.c_int32, [vp]),
+    "shz_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
+    "shz_timer_start": (C.c_int32, [vp, C.c_int32]),
+    "shz_timer_stop": (C.c_int32, [vp, C.c_int32, C.POINTER(C.c_float)]),
+    "shz_set_profiling": (C.c_int32, [vp, C.c_int32]),
+    "shz_get_kernel_ms": (C.c_int32, [vp, C.c_int32, C.POINTER(C.c_float), u32p]),
+    "shz_synth_pcm": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, vp]),
+    "shz_frame_count": (C.c_uint32, [C.c_uint64]),
+    "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
+    "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
+    "shz_peaks_from_db": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_double, vp, vp, C.c_uint64, u64p]),
+    "shz_pair_hash": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
+    "shz_fingerprint_batch": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32,
+                                          vp, vp, u64p, C.c_uint64, u64p]),
+    "shz_sha1_prefix": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "shz_table_create": (C.c_int32, [vp, C.POINTER(vp)]),
+    "shz_table_destroy": (C.c_int32, [vp]),
+    "shz_table_insert": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, C.c_uint32]),
+    "shz_table_insert_clips": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "shz_table_finalize": (C.c_int32, [vp]),
+    "shz_table_rows": (C.c_int32, [vp, u64p, u64p]),
+    "shz_table_export": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, u64p]),
+    "shz_table_lookup": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]),
+    "shz_table_song_rows": (C.c_int32, [vp, C.c_uint32, u64p]),
+    "shz_match_batch": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    vp, vp, vp, vp, vp, vp, vp]),
+    "shz_match_stats": (C.c_int32, [vp, u64p, u64p, u64p]),
+    "shz_comm_unique_id": (C.c_int32, [vp]),
+    "shz_comm_create": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "shz_comm_destroy": (C.c_int32, [vp]),
+    "shz_table_allgather": (C.c_int32, [vp, vp, u64p]),
+    "shz_comm_barrier": (C.c_int32, [vp]),
+}
+
+
+class ShzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libshz error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libshz.so (built in-tree by __graft_entry__.build() / make -C shazam_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `make -C shazam_amd/csrc` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    """void* of a numpy array (or pass through ints / None)."""
+    if a is None:
+        return None
+    if isinstance(a, (int,)):
+        return C.c_void_p(a)
+    if isinstance(a, DevBuf):
+        return C.c_void_p(a.ptr)
+    return C.c_void_p(a.ctypes.data)
+
+
+class DevBuf:
+    """Caller-owned device allocation (shz_dev_alloc)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = vp()
+        ctx.check(lib().shz_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.check(lib().shz_dev_free(self.ctx.h, vp(self.ptr)))
+        self.ptr = None
+
+    def upload(self, arr: np.ndarray, offset_bytes: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        self.ctx.check(lib().shz_copy_h2d(self.ctx.h, vp(self.ptr + offset_bytes), ptr(arr), arr.nbytes))
+
+    def download(self, dtype, count: int, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        self.ctx.check(lib().shz_copy_d2h(self.ctx.h, ptr(out), vp(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One (device, stream).  Not thread-safe; use one per thread/process."""
+
+    def __init__(self, device_id: int = 0):
+        self.h = None
+        h = vp()
+        rc = lib().shz_ctx_create(device_id, C.byref(h))
+        if rc != OK:
+            raise ShzError(rc, f"shz_ctx_create(device {device_id}) failed -- is a ROCm GPU visible?")
+        self.h = h
+        self.device_id = device_id
+
+    def check(self, rc):
+        if rc != OK:
+            raise ShzError(rc, (lib().shz_last_error(self.h) or b"").decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            lib().shz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- info / memory -------------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        hbm, cus, clk = C.c_uint64(), C.c_int32(), C.c_int32()
+        self.check(lib().shz_device_info(self.h, name, 256, C.byref(hbm), C.byref(cus), C.byref(clk)))
+        return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cus.value, "clock_khz": clk.value}
+
+    def alloc(self, nbytes) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def sync(self):
+        self.check(lib().shz_sync(self.h))
+
+    def set_workspace_limit(self, nbytes):
+        self.check(lib().shz_set_workspace_limit(self.h, int(nbytes)))
+
+    def timer_start(self, slot=0):
+        self.check(lib().shz_timer_start(self.h, slot))
+
+    def timer_stop(self, slot=0) -> float:
+        ms = C.c_float()
+        self.check(lib().shz_timer_stop(self.h, slot, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on: bool):
+        self.check(lib().shz_set_profiling(self.h, 1 if on else 0))
+
+    def kernel_ms(self):
+        names = ["stft_psd_db", "peak_pick", "peak_expand", "pair_hash"]
+        out = {}
+        for i, n in enumerate(names):
+            ms, k = C.c_float(), C.c_uint32()
+            self.check(lib().shz_get_kernel_ms(self.h, i, C.byref(ms), C.byref(k)))
+            out[n] = (ms.value, k.value)
+        return out
+
+    # ---- synthetic PCM ---------------------------------------------------------------------
+    def synth_pcm(self, seed, clip0, n_clips, n_samples, tone_amp=0, noise_amp=8000, start=0, out: DevBuf = None) -> DevBuf:
+        if out is None:
+            out = self.alloc(int(n_clips) * int(n_samples) * 2)
+        done = 0
+        while done < n_clips:  # the kernel takes at most 65535 clips per launch
+            k = min(65535, n_clips - done)
+            self.check(lib().shz_synth_pcm(self.h, seed, clip0 + done, k, n_samples, tone_amp, noise_amp, start,
+                                           vp(out.ptr + done * n_samples * 2)))
+            done += k
+        return out
+
+    # ---- extraction ---------------------------------------------------------------------------
+    @staticmethod
+    def _clip_off(clip_off, n_clips=None):
+        co = np.ascontiguousarray(clip_off, np.uint64)
+        assert co.ndim == 1 and len(co) >= 1
+        return co, len(co) - 1
+
+    def stft_db(self, pcm, clip_off, fs=44100, pcm_device=False):
+        co, nc = self._clip_off(clip_off)
+        frames = [int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc)]
+        out = np.empty(sum(frames) * NBINS, np.float64)
+        cnt = C.c_uint64()
+        self.check(lib().shz_stft_db(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs, PCM_DEVICE if pcm_device else 0,
+                                     ptr(out), out.size, C.byref(cnt)))
+        res, pos = [], 0
+        for f in frames:
+            res.append(out[pos:pos + f * NBINS].reshape(NBINS, f))
+            pos += f * NBINS
+        return res
+
+    def peaks(self, pcm, clip_off, fs=44100, amp_min=10.0, pcm_device=False):
+        co, nc = self._clip_off(clip_off)
+        total_frames = sum(int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc))
+        cap = max(1024, total_frames * 16)
+        flags = PCM_DEVICE if pcm_device else 0
+        while True:
+            pf, pt = np.empty(cap, np.uint16), np.empty(cap, np.uint32)
+            po, cnt = np.zeros(nc + 1, np.uint64), C.c_uint64()
+            rc = lib().shz_peaks(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs, float(amp_min), flags, ptr(pf), ptr(pt),
+                                 po.ctypes.data_as(u64p), cap, C.byref(cnt))
+            if rc == E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self.check(rc)
+            n = int(cnt.value)
+            return pf[:n], pt[:n], po
+
+    def peaks_from_db(self, arr2d, amp_min=10.0):
+        a = np.ascontiguousarray(arr2d, np.float64)
+        assert a.ndim == 2
+        cap = max(1024, a.shape[1] * 16)
+        while True:
+            of, ot, cnt = np.empty(cap, np.uint32), np.empty(cap, np.uint32), C.c_uint64()
+            rc = lib().shz_peaks_from_db(self.h, ptr(a), a.shape[0], a.shape[1], float(amp_min), ptr(of), ptr(ot), cap, C.byref(cnt))
+            if rc == E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self.check(rc)
+            n = int(cnt.value)
+            return of[:n], ot[:n]
+
+    def pair_hash(self, peak_f, peak_t, peak_off, fan_value=5):
+        pf = np.ascontiguousarray(peak_f, np.uint16)
+        pt = np.ascontiguousarray(peak_t, np.uint32)
+        po = np.ascontiguousarray(peak_off, np.uint64)
+        nc = len(po) - 1
+        cap = max(16, len(pf) * max(fan_value - 1, 0))
+        k, t1 = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        ho, cnt = np.zeros(nc + 1, np.uint64), C.c_uint64()
+        self.check(lib().shz_pair_hash(self.h, ptr(pf), ptr(pt), po.ctypes.data_as(u64p), nc, fan_value, ptr(k), ptr(t1),
+                                       ho.ctypes.data_as(u64p), cap, C.byref(cnt)))
+        n = int(cnt.value)
+        return k[:n], t1[:n], ho
+
+    def fingerprint_batch(self, pcm, clip_off, fs=44100, amp_min=10.0, fan_value=5, pcm_device=False,
+                          out_key: DevBuf = None, out_t1: DevBuf = None, cap=None):
+        """(key32, t1, hash_off).  With out_key/out_t1 DevBufs the hashes stay on the device and the
+        returned arrays are None; hash_off (host) and the count are always returned."""
+        co, nc = self._clip_off(clip_off)
+        flags = PCM_DEVICE if pcm_device else 0
+        ho, cnt = np.zeros(nc + 1, np.uint64), C.c_uint64()
+        if out_key is not None:
+            cap = int(cap if cap is not None else out_key.nbytes // 4)
+            self.check(lib().shz_fingerprint_batch(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs, float(amp_min), fan_value,
+                                                   flags | OUT_DEVICE, ptr(out_key), ptr(out_t1), ho.ctypes.data_as(u64p), cap,
+                                                   C.byref(cnt)))
+            return None, None, ho, int(cnt.value)
+        total_frames = sum(int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc))
+        cap = max(1024, total_frames * 40)
+        while True:
+            k, t1 = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+            rc = lib().shz_fingerprint_batch(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs, float(amp_min), fan_value, flags,
+                                             ptr(k), ptr(t1), ho.ctypes.data_as(u64p), cap, C.byref(cnt))
+            if rc == E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self.check(rc)
+            n = int(cnt.value)
+            return k[:n], t1[:n], ho, n
+
+    def sha1_prefix(self, key32, device=False, n=None) -> np.ndarray:
+        if not device:
+            key32 = np.ascontiguousarray(key32, np.uint32)
+            n = len(key32)
+        out = np.empty((int(n), 10), np.uint8)
+        self.check(lib().shz_sha1_prefix(self.h, ptr(key32), int(n), IN_DEVICE if device else 0, ptr(out)))
+        return out
+
+
+class Table:
+    """HBM-resident fingerprints table: rows (key32, song_id, offset)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.h = ctx, None
+        h = vp()
+        ctx.check(lib().shz_table_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().shz_table_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def insert(self, key32, sid, off):
+        k = np.ascontiguousarray(key32, np.uint32)
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(sid, np.uint32), k.shape))
+        o = np.ascontiguousarray(off, np.uint32)
+        assert k.shape == s.shape == o.shape
+        self.ctx.check(lib().shz_table_insert(self.h, ptr(k), ptr(s), ptr(o), len(k), 0))
+
+    def insert_clips(self, key32, t1, hash_off, sid0, device=False):
+        ho = np.ascontiguousarray(hash_off, np.uint64)
+        if not device:
+            key32 = np.ascontiguousarray(key32, np.uint32)
+            t1 = np.ascontiguousarray(t1, np.uint32)
+        self.ctx.check(lib().shz_table_insert_clips(self.h, ptr(key32), ptr(t1), ho.ctypes.data_as(u64p), len(ho) - 1, sid0,
+                                                    IN_DEVICE if device else 0))
+
+    def finalize(self):
+        self.ctx.check(lib().shz_table_finalize(self.h))
+
+    def rows(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.ctx.check(lib().shz_table_rows(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def export(self):
+        n, _ = self.rows()
+        k, s, o, cnt = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint32), C.c_uint64()
+        self.ctx.check(lib().shz_table_export(self.h, ptr(k), ptr(s), ptr(o), n, C.byref(cnt)))
+        return k, s, o
+
+    def lookup(self, keys):
+        """Rows of the listed keys: (key32, sid, off) arrays, grouped in key-list order."""
+        kk = np.ascontiguousarray(keys, np.uint32)
+        cap = max(1024, 4 * len(kk))
+        while True:
+            k, s, o, cnt = np.empty(cap, np.uint32), np.empty(cap, np.uint32), np.empty(cap, np.uint32), C.c_uint64()
+            rc = lib().shz_table_lookup(self.h, ptr(kk), len(kk), ptr(k), ptr(s), ptr(o), cap, C.byref(cnt))
+            if rc == E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self.ctx.check(rc)
+            n = int(cnt.value)
+            return k[:n], s[:n], o[:n]
+
+    def song_rows(self, sid) -> int:
+        n = C.c_uint64()
+        self.ctx.check(lib().shz_table_song_rows(self.h, int(sid), C.byref(n)))
+        return n.value
+
+    def allgather(self, comm: "Comm") -> int:
+        b = C.c_uint64()
+        self.ctx.check(lib().shz_table_allgather(self.h, comm.h, C.byref(b)))
+        return b.value
+
+    def match(self, key32, q_off, query_off, topn=2):
+        """Batched return_matches + align_matches.  Returns dict of arrays (see shz.h)."""
+        k = np.ascontiguousarray(key32, np.uint32)
+        o = np.ascontiguousarray(q_off, np.uint32)
+        qo = np.ascontiguousarray(query_off, np.uint64)
+        nq = len(qo) - 1
+        res = {
+            "sid": np.zeros((nq, topn), np.uint32), "delta": np.zeros((nq, topn), np.int32),
+            "aligned": np.zeros((nq, topn), np.uint32), "dedup": np.zeros((nq, topn), np.uint32),
+            "nres": np.zeros(nq, np.uint32), "nhash": np.zeros(nq, np.uint32), "npairs": np.zeros(nq, np.uint64)}
+        self.ctx.check(lib().shz_match_batch(self.ctx.h, self.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, topn, 0,
+                                             ptr(res["sid"]), ptr(res["delta"]), ptr(res["aligned"]), ptr(res["dedup"]),
+                                             ptr(res["nres"]), ptr(res["nhash"]), ptr(res["npairs"])))
+        return res
+
+    def match_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx.check(lib().shz_match_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rows_scanned": a.value, "pairs": b.value, "distinct_keys": c.value}
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    rc = lib().shz_comm_unique_id(buf)
+    if rc != OK:
+        raise ShzError(rc, "shz_comm_unique_id failed (librccl.so not loadable?)")
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator, one rank per GPU."""
+
+    def __init__(self, ctx: Context, unique_id: bytes, rank: int, nranks: int):
+        self.ctx, self.h = ctx, None
+        assert len(unique_id) == 128
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = vp()
+        ctx.check(lib().shz_comm_create(ctx.h, idb, rank, nranks, C.byref(h)))
+        self.h, self.rank, self.nranks = h, rank, nranks
+
+    def barrier(self):
+        self.ctx.check(lib().shz_comm_barrier(self.h))
+
+    def close(self):
+        if self.h and self.ctx.h:
+            lib().shz_comm_destroy(self.h)
+        self.h = None

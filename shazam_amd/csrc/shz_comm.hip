@@ -1,0 +1,137 @@
+// RCCL communicator for the multi-GPU database build.  librccl.so is opened
+// lazily with dlopen so single-GPU users never load it; one rank per GPU, the ncclUniqueId
+// travels between ranks through the host (torch.distributed store / any side channel).
+#include <dlfcn.h>
+
+#include "shz_internal.h"
+
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+// ncclDataType_t values used here (rccl.h): ncclUint8 = 1, ncclUint32 = 3, ncclUint64 = 5
+enum { NCCL_U8 = 1, NCCL_U32 = 3, NCCL_U64 = 5 };
+
+struct rccl_api {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static rccl_api* rccl() {
+  static rccl_api api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      *(void**)&api.GetUniqueId = dlsym(api.lib, "ncclGetUniqueId");
+      *(void**)&api.CommInitRank = dlsym(api.lib, "ncclCommInitRank");
+      *(void**)&api.CommDestroy = dlsym(api.lib, "ncclCommDestroy");
+      *(void**)&api.AllGather = dlsym(api.lib, "ncclAllGather");
+      *(void**)&api.Broadcast = dlsym(api.lib, "ncclBroadcast");
+      *(void**)&api.GroupStart = dlsym(api.lib, "ncclGroupStart");
+      *(void**)&api.GroupEnd = dlsym(api.lib, "ncclGroupEnd");
+      *(void**)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Broadcast) {
+        dlclose(api.lib);
+        api.lib = nullptr;
+      }
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+
+struct shz_comm {
+  shz_ctx* ctx;
+  ncclComm_t comm;
+  int rank, nranks;
+};
+
+#define SHZ_NCCL(ctx, call)                                                                          \
+  do {                                                                                               \
+    ncclResult_t _r = (call);                                                                        \
+    if (_r != 0) SHZ_FAIL(ctx, SHZ_E_RCCL, "%s failed: %s", #call,                                    \
+                          rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "rccl error");       \
+  } while (0)
+
+extern "C" int32_t shz_comm_unique_id(uint8_t id_out[128]) {
+  rccl_api* r = rccl();
+  if (!r || !id_out) return SHZ_E_RCCL;
+  ncclUniqueId id;
+  if (r->GetUniqueId(&id) != 0) return SHZ_E_RCCL;
+  memcpy(id_out, id.internal, 128);
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_comm_create(shz_ctx* ctx, const uint8_t idb[128], int32_t rank, int32_t nranks, shz_comm** out) {
+  if (!ctx || !idb || !out || nranks < 1 || rank < 0 || rank >= nranks) return SHZ_E_INVALID;
+  rccl_api* r = rccl();
+  if (!r) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so could not be loaded: %s", dlerror());
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(id.internal, idb, 128);
+  ncclComm_t c;
+  SHZ_NCCL(ctx, r->CommInitRank(&c, nranks, id, rank));
+  shz_comm* cm = new shz_comm{ctx, c, rank, nranks};
+  *out = cm;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_comm_destroy(shz_comm* c) {
+  if (!c) return SHZ_E_INVALID;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  rccl()->CommDestroy(c->comm);
+  delete c;
+  return SHZ_OK;
+}
+
+// internal: used by shz_table_allgather (shz_table.hip)
+int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks) {
+  *rank = c->rank;
+  *nranks = c->nranks;
+  return SHZ_OK;
+}
+
+// all-gather of equal-sized byte blocks: recv must hold nranks*bytes
+int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes) {
+  shz_ctx* ctx = c->ctx;
+  SHZ_NCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, NCCL_U8, c->comm, ctx->stream));
+  return SHZ_OK;
+}
+
+// variable-size all-gather as one grouped set of broadcasts: rank r's block lands at
+// d_recv + displ[r]; every peer pair moves data directly (mesh over xGMI, no ring staging).
+int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
+                                  const uint64_t* displ) {
+  shz_ctx* ctx = c->ctx;
+  rccl_api* r = rccl();
+  if (r->GroupStart) SHZ_NCCL(ctx, r->GroupStart());
+  for (int p = 0; p < c->nranks; ++p) {
+    if (counts[p] == 0) continue;
+    const void* src = (p == c->rank) ? d_send : (const void*)((char*)d_recv + displ[p]);
+    SHZ_NCCL(ctx, r->Broadcast(src, (char*)d_recv + displ[p], counts[p], NCCL_U8, p, c->comm, ctx->stream));
+  }
+  if (r->GroupEnd) SHZ_NCCL(ctx, r->GroupEnd());
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_comm_barrier(shz_comm* c) {
+  if (!c) return SHZ_E_INVALID;
+  shz_ctx* ctx = c->ctx;
+  void* p;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64 + 8ull * c->nranks, &p));
+  SHZ_TRY(shz_comm_allgather_bytes(c, p, (char*)p + 64, 8));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}

@@ -1,0 +1,268 @@
+// Context, device memory, timers and the synthetic-PCM generator of libshz.so.
+#include <math.h>
+
+#include "shz_internal.h"
+
+extern "C" const char* shz_version(void) { return "shz 0.1 (gfx950)"; }
+
+int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out) {
+  shz_buf& b = ctx->ws[slot];
+  if (bytes == 0) bytes = 256;
+  if (b.cap < bytes) {
+    if (b.p) {
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      SHZ_HIP(ctx, hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    uint64_t want = (bytes + (bytes >> 3) + 4095) & ~uint64_t(4095);  // 12.5 % slack against regrowth
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      want = (bytes + 4095) & ~uint64_t(4095);
+      e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "hipMalloc(%llu) for workspace slot %d failed: %s",
+                                  (unsigned long long)want, slot, hipGetErrorString(e));
+    b.cap = want;
+  }
+  *out = b.p;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
+  if (!out) return SHZ_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return SHZ_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return SHZ_E_HIP;
+  shz_ctx* ctx = new shz_ctx();
+  ctx->device = device_id;
+  if (hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return SHZ_E_HIP;
+  }
+  ctx->ws_limit = ctx->prop.totalGlobalMem / 4;
+  // constant tables, computed in long double and rounded once
+  std::vector<double> win(SHZ_NFFT);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  double sumsq = 0.0;
+  for (int i = 0; i < SHZ_NFFT; ++i) {
+    // np.hanning(M): 0.5 + 0.5*cos(pi*n/(M-1)), n = 1-M, 3-M, ...  (mlab.window_hanning)
+    long double nn = (long double)(1 - SHZ_NFFT + 2 * i);
+    win[i] = (double)(0.5L + 0.5L * cosl(pi * nn / (long double)(SHZ_NFFT - 1)));
+  }
+  for (int i = 0; i < SHZ_NFFT; ++i) sumsq += win[i] * win[i];
+  ctx->win_sumsq = sumsq;
+  std::vector<double2> tw(SHZ_NFFT / 4 + 1);
+  for (int k = 0; k <= SHZ_NFFT / 4; ++k) {
+    long double a = -2.0L * pi * (long double)k / (long double)SHZ_NFFT;
+    tw[k].x = (double)cosl(a);
+    tw[k].y = (double)sinl(a);
+  }
+  std::vector<int16_t> lut(4096);
+  for (int i = 0; i < 4096; ++i) lut[i] = (int16_t)lrint(32767.0 * sin(2.0 * M_PI * (double)i / 4096.0));
+  bool ok = hipMalloc(&ctx->d_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&
+            hipMalloc(&ctx->d_twiddle, sizeof(double2) * tw.size()) == hipSuccess &&
+            hipMalloc(&ctx->d_sine_lut, sizeof(int16_t) * 4096) == hipSuccess &&
+            hipMemcpy(ctx->d_window, win.data(), sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_twiddle, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_sine_lut, lut.data(), sizeof(int16_t) * 4096, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipEventCreate(&ctx->pev[0]) == hipSuccess && hipEventCreate(&ctx->pev[1]) == hipSuccess;
+  if (!ok) {
+    shz_ctx_destroy(ctx);
+    return SHZ_E_HIP;
+  }
+  *out = ctx;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
+  if (!ctx) return SHZ_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->ws)
+    if (b.p) (void)hipFree(b.p);
+  if (ctx->d_window) (void)hipFree(ctx->d_window);
+  if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+  if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
+  if (ctx->tev_init)
+    for (auto& e : ctx->tev) {
+      (void)hipEventDestroy(e[0]);
+      (void)hipEventDestroy(e[1]);
+    }
+  if (ctx->pev[0]) (void)hipEventDestroy(ctx->pev[0]);
+  if (ctx->pev[1]) (void)hipEventDestroy(ctx->pev[1]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SHZ_OK;
+}
+
+extern "C" const char* shz_last_error(shz_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int32_t shz_device_info(shz_ctx* ctx, char* name, uint64_t name_cap, uint64_t* hbm_bytes,
+                                   int32_t* compute_units, int32_t* clock_khz) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (name && name_cap) {
+    snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+  if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = ctx->prop.clockRate;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_dev_alloc(shz_ctx* ctx, uint64_t bytes, void** dptr) {
+  if (!ctx || !dptr) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 256);
+  if (e != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_dev_free(shz_ctx* ctx, void* dptr) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (!dptr) return SHZ_OK;
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SHZ_HIP(ctx, hipFree(dptr));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_copy_h2d(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return SHZ_E_INVALID;
+  if (!bytes) return SHZ_OK;
+  SHZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_copy_d2h(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return SHZ_E_INVALID;
+  if (!bytes) return SHZ_OK;
+  SHZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_sync(shz_ctx* ctx) {
+  if (!ctx) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_set_workspace_limit(shz_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return SHZ_E_INVALID;
+  ctx->ws_limit = bytes ? bytes : ctx->prop.totalGlobalMem / 4;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_timer_start(shz_ctx* ctx, int32_t slot) {
+  if (!ctx || slot < 0 || slot >= 16) return SHZ_E_INVALID;
+  if (!ctx->tev_init) {
+    for (auto& e : ctx->tev) {
+      SHZ_HIP(ctx, hipEventCreate(&e[0]));
+      SHZ_HIP(ctx, hipEventCreate(&e[1]));
+    }
+    ctx->tev_init = true;
+  }
+  SHZ_HIP(ctx, hipEventRecord(ctx->tev[slot][0], ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_timer_stop(shz_ctx* ctx, int32_t slot, float* ms) {
+  if (!ctx || slot < 0 || slot >= 16 || !ctx->tev_init) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipEventRecord(ctx->tev[slot][1], ctx->stream));
+  SHZ_HIP(ctx, hipEventSynchronize(ctx->tev[slot][1]));
+  float v = 0;
+  SHZ_HIP(ctx, hipEventElapsedTime(&v, ctx->tev[slot][0], ctx->tev[slot][1]));
+  if (ms) *ms = v;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled) {
+  if (!ctx) return SHZ_E_INVALID;
+  ctx->profiling = enabled != 0;
+  for (int i = 0; i < 8; ++i) {
+    ctx->kernel_ms[i] = 0;
+    ctx->kernel_launches[i] = 0;
+  }
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t* launches) {
+  if (!ctx || which < 0 || which >= 8) return SHZ_E_INVALID;
+  if (total_ms) *total_ms = ctx->kernel_ms[which];
+  if (launches) *launches = ctx->kernel_launches[which];
+  return SHZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Synthetic PCM: integer-only generator, bit-identical numpy twin in oracle/synth.py.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+#define SYN_NOTE_SHIFT 14
+#define SYN_NPART 6
+#define SYN_OM_MIN 10713046u
+#define SYN_OM_MAX 428521855u
+
+// one thread = 8 consecutive samples (one 16-byte store); grid.y = clip
+__global__ __launch_bounds__(256) void synth_pcm_kernel(int16_t* __restrict__ out, uint64_t seed, uint64_t clip0,
+                                                        uint64_t n_samples, uint64_t start, int tone_amp,
+                                                        int noise_amp, const int16_t* __restrict__ lut) {
+  const uint64_t clip = blockIdx.y;
+  const uint64_t key = splitmix64(seed * 0xD6E8FEB86659FD93ull + clip0 + clip);
+  int16_t* dst = out + clip * n_samples;
+  for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; base < n_samples;
+       base += (uint64_t)gridDim.x * blockDim.x * 8) {
+    int16_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t n = start + base + i;
+      long long acc = 0;
+      if (noise_amp > 0) {
+        uint64_t u = splitmix64(key + n) >> 32;
+        acc += (long long)((u * (uint64_t)(2 * noise_amp)) >> 32) - noise_amp;
+      }
+      if (tone_amp > 0) {
+        const uint64_t seg = n >> SYN_NOTE_SHIFT, m = n & ((1u << SYN_NOTE_SHIFT) - 1);
+        long long s = 0;
+#pragma unroll
+        for (int k = 0; k < SYN_NPART; ++k) {
+          uint64_t r = splitmix64(~key + seg * 8 + (uint64_t)k);
+          uint64_t om = (uint64_t)SYN_OM_MIN + (((r >> 32) * (uint64_t)(SYN_OM_MAX - SYN_OM_MIN)) >> 32);
+          uint32_t ph = (uint32_t)(r + m * om);
+          s += lut[ph >> 20];
+        }
+        acc += (s * tone_amp) >> 17;
+      }
+      acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+      v[i] = (int16_t)acc;
+    }
+    if (base + 8 <= n_samples && ((clip * n_samples + base) & 7) == 0) {
+      *reinterpret_cast<uint4*>(dst + base) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      for (int i = 0; i < 8 && base + i < n_samples; ++i) dst[base + i] = v[i];
+    }
+  }
+}
+
+extern "C" int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
+                                 int32_t tone_amp, int32_t noise_amp, uint64_t start_sample, int16_t* dev_out) {
+  if (!ctx || !dev_out) return SHZ_E_INVALID;
+  if (n_clips == 0 || n_samples == 0) return SHZ_OK;
+  if (n_clips > 65535) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_pcm: at most 65535 clips per call (got %u)", n_clips);
+  if (tone_amp < 0 || noise_amp < 0 || tone_amp > 10000 || noise_amp > 32768)
+    SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_pcm: tone_amp in [0,10000], noise_amp in [0,32768]");
+  uint64_t per = (n_samples + 8 * 256 - 1) / (8 * 256);
+  dim3 grid((unsigned)(per > 4096 ? 4096 : per), n_clips);
+  hipLaunchKernelGGL(synth_pcm_kernel, grid, dim3(256), 0, ctx->stream, dev_out, seed, clip0, n_samples, start_sample,
+                     tone_amp, noise_amp, ctx->d_sine_lut);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}

@@ -1,0 +1,836 @@
+// Fingerprint extraction on gfx950: PCM -> STFT power (fp64) -> dB -> 21x21 local-max peaks ->
+// ordered peak list -> peak-pair keys.  Restates (from the spec in SURVEY.md 8a, not from code)
+//   mlab.specgram(x, 4096, Fs, window_hanning, 2048)[0]         __init__.py:232-237, mlab:213-373
+//   10*log10 where != 0                                          __init__.py:241
+//   get_2D_peaks (21x21 max filter == value, > amp_min)          __init__.py:116-177
+//   generate_hashes (time-major order, 4 partners, dt <= 200)    __init__.py:179-210
+//
+// Data layout in HBM (per sub-batch):
+//   pcm      int16, clips concatenated                                        (input)
+//   db       f64 [frame][DB_STRIDE=2056], frames of all clips concatenated   (stage buffer)
+//   mask     u64 [frame][n_slabs][4]  one bit per (frame, bin): peak          (stage buffer)
+//   peak_f/t u16/u32 in (clip, t asc, f asc) order                             (stage buffer)
+//   key32/t1 u32 in the reference's generation order                           (output)
+#include <algorithm>
+
+#include "shz_internal.h"
+
+#define DB_STRIDE 2056  // 2049 bins padded so every row starts 64-byte aligned
+
+// ======================================================================================
+// K1: stft_psd_db.  One workgroup (256 threads) per frame, persistent over frames.
+// real 4096-FFT = complex 2048-FFT (Stockham radix 8,8,8,4 through LDS) + split post-pass.
+// LDS: 2304 double2 data (index padded i + i/8 against bank conflicts) + 1025 double2 twiddles.
+// ======================================================================================
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cmul_negi(cplx a) { return make_double2(a.y, -a.x); }  // a * (-i)
+
+__device__ __forceinline__ void dft4(cplx& c0, cplx& c1, cplx& c2, cplx& c3) {
+  cplx d0 = cadd(c0, c2), d2 = csub(c0, c2), d1 = cadd(c1, c3), d3 = cmul_negi(csub(c1, c3));
+  c0 = cadd(d0, d1);
+  c1 = cadd(d2, d3);
+  c2 = csub(d0, d1);
+  c3 = csub(d2, d3);
+}
+
+// forward 8-point DFT, in place, natural output order
+__device__ __forceinline__ void dft8(cplx* v) {
+  const double s = 0.70710678118654752440;
+  cplx b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
+  cplx b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
+  cplx b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
+  cplx b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
+  b5 = make_double2((b5.x + b5.y) * s, (b5.y - b5.x) * s);   // * W8^1
+  b6 = cmul_negi(b6);                                        // * W8^2
+  b7 = make_double2((b7.y - b7.x) * s, -(b7.x + b7.y) * s);  // * W8^3
+  dft4(b0, b1, b2, b3);
+  dft4(b4, b5, b6, b7);
+  v[0] = b0; v[1] = b4; v[2] = b1; v[3] = b5; v[4] = b2; v[5] = b6; v[6] = b3; v[7] = b7;
+}
+
+#define LPAD(i) ((i) + ((i) >> 3))
+
+struct stft_args {
+  const int16_t* pcm;
+  const uint64_t* clip_soff;   // [n_clips] first sample of each clip (into pcm)
+  const uint64_t* clip_len;    // [n_clips] samples
+  const uint32_t* clip_foff;   // [n_clips+1] first frame of each clip (sub-batch numbering)
+  uint32_t n_clips;
+  uint32_t total_frames;
+  double* out;                 // [total_frames][DB_STRIDE]
+  const double* window;        // [4096]
+  const cplx* tw;              // [1025] W4096^k
+  double scale;                // 0.25 / (Fs * sum(w^2))
+};
+
+__global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
+  __shared__ cplx lds[2304 + 1025];
+  cplx* buf = lds;
+  cplx* tw = lds + 2304;
+  const int j = threadIdx.x;
+  for (int i = j; i < 1025; i += 256) tw[i] = a.tw[i];
+  __syncthreads();
+
+  for (uint32_t g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
+    // clip of frame g (uniform binary search over the frame offsets)
+    uint32_t lo = 0, hi = a.n_clips;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (a.clip_foff[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo;
+    const uint64_t clen = a.clip_len[c];
+    const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[c]) * SHZ_HOP;
+    const int16_t* src = a.pcm + a.clip_soff[c] + s_in_clip;
+    const uint64_t avail = clen > s_in_clip ? clen - s_in_clip : 0;  // samples readable from src
+
+    cplx v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int n = j + 256 * t;  // complex index; samples 2n, 2n+1
+      const double2 w = *reinterpret_cast<const double2*>(a.window + 2 * n);
+      double x0, x1;
+      if (avail >= SHZ_NFFT) {
+        x0 = (double)src[2 * n];
+        x1 = (double)src[2 * n + 1];
+      } else {  // zero padding of short inputs (mlab:268-271)
+        x0 = (uint64_t)(2 * n) < avail ? (double)src[2 * n] : 0.0;
+        x1 = (uint64_t)(2 * n + 1) < avail ? (double)src[2 * n + 1] : 0.0;
+      }
+      v[t] = make_double2(x0 * w.x, x1 * w.y);
+    }
+    // pass 1: Ns = 1 (no twiddles)
+    dft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[9 * j + r] = v[r];  // LPAD(8j + r)
+    __syncthreads();
+
+    // pass 2: Ns = 8, twiddles W_64^(k t) = W4096^(64 k t)
+    {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      __syncthreads();
+      const int k = j & 7;
+      const cplx w1 = tw[64 * k], w2 = tw[128 * k];
+      const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
+      v[1] = cmul(v[1], w1);
+      v[2] = cmul(v[2], w2);
+      v[3] = cmul(v[3], w3);
+      v[4] = cmul(v[4], w4);
+      v[5] = cmul(v[5], cmul(w1, w4));
+      v[6] = cmul(v[6], cmul(w2, w4));
+      v[7] = cmul(v[7], cmul(w3, w4));
+      dft8(v);
+      const int base = ((j >> 3) << 6) + k;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[LPAD(base + 8 * r)] = v[r];
+      __syncthreads();
+    }
+    // pass 3: Ns = 64, twiddles W_512^(k t) = W4096^(8 k t)
+    {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      __syncthreads();
+      const int k = j & 63;
+      const cplx w1 = tw[8 * k], w2 = tw[16 * k];
+      const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
+      v[1] = cmul(v[1], w1);
+      v[2] = cmul(v[2], w2);
+      v[3] = cmul(v[3], w3);
+      v[4] = cmul(v[4], w4);
+      v[5] = cmul(v[5], cmul(w1, w4));
+      v[6] = cmul(v[6], cmul(w2, w4));
+      v[7] = cmul(v[7], cmul(w3, w4));
+      dft8(v);
+      const int base = ((j >> 6) << 9) + k;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[LPAD(base + 64 * r)] = v[r];
+      __syncthreads();
+    }
+    // pass 4: Ns = 512, radix 4, two butterflies per thread (k = j and k = j + 256);
+    // twiddles W_2048^(k t) = W4096^(2 k t)
+    {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = j + 256 * h;
+        const cplx w1 = tw[2 * k];
+        const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+        cplx c0 = v[h], c1 = cmul(v[h + 2], w1), c2 = cmul(v[h + 4], w2), c3 = cmul(v[h + 6], w3);
+        dft4(c0, c1, c2, c3);
+        buf[LPAD(k)] = c0;
+        buf[LPAD(k + 512)] = c1;
+        buf[LPAD(k + 1024)] = c2;
+        buf[LPAD(k + 1536)] = c3;
+      }
+      __syncthreads();
+    }
+    // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale, dB
+    double* orow = a.out + (uint64_t)g * DB_STRIDE;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int k = j + 256 * m;
+      if (m == 4 && j != 0) break;
+      const cplx zk = buf[LPAD(k)];
+      const cplx zm = buf[LPAD((2048 - k) & 2047)];
+      const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
+      const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
+      const cplx wo = cmul(tw[k], o);
+      const cplx xa = cadd(e, wo), xb = csub(e, wo);
+      double pa = fma(xa.x, xa.x, xa.y * xa.y) * a.scale;
+      double pb = fma(xb.x, xb.x, xb.y * xb.y) * a.scale;
+      if (k != 0) {  // bins 1..2047 doubled (mlab:339-345); bin 2048 pairs with k = 0
+        pa *= 2.0;
+        pb *= 2.0;
+      }
+      orow[k] = (pa != 0.0) ? 10.0 * log10(pa) : 0.0;
+      if (k != 1024) orow[2048 - k] = (pb != 0.0) ? 10.0 * log10(pb) : 0.0;
+    }
+    __syncthreads();  // buf is rewritten by the next frame's pass 1
+  }
+}
+
+// ======================================================================================
+// K2: peak_pick.  Workgroup = (clip segment, slab of PK_SW bins); streams frames in time with a
+// 21-deep register history per thread; the 21-wide frequency max goes through an LDS row.
+// peak <=> A == max over 21x21 window clipped to the array, and A > amp_min (ties all count).
+// ======================================================================================
+#define PK_SW 228
+#define PK_COLS 248
+#define PK_PF 7
+
+struct peak_seg {
+  uint32_t gframe0;  // global (sub-batch) frame index of the clip's frame 0
+  uint32_t nframes;  // frames in the clip
+  uint32_t t0, t1;   // output frames [t0, t1)
+};
+
+__global__ __launch_bounds__(256) void peak_pick_kernel(const double* __restrict__ A, uint32_t row_stride,
+                                                        uint32_t n_bins, const peak_seg* __restrict__ segs,
+                                                        uint32_t n_slabs, double amp_min,
+                                                        uint64_t* __restrict__ mask) {
+  __shared__ double row[2][PK_COLS + 8];
+  const peak_seg sg = segs[blockIdx.y];
+  const uint32_t slab = blockIdx.x;
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const double NEG = -__builtin_inf();
+  // thread -> column: outputs first so that wave w's ballot covers slab bins [64w, 64w+63]
+  int li;  // index in the LDS row = column - (slab*PK_SW - 10)
+  if (j < PK_SW) li = j + 10;
+  else if (j < PK_SW + 10) li = j - PK_SW;
+  else li = j - 10 + 10;  // j in [238,248) -> li in [238,248)
+  const long long col = (long long)slab * PK_SW - 10 + li;
+  const bool loads = j < PK_COLS && col >= 0 && col < (long long)n_bins;
+  const bool is_out = j < PK_SW && col < (long long)n_bins;
+  const int lo = (int)sg.t0 - 10 > 0 ? (int)sg.t0 - 10 : 0;
+  const int hi = (int)(sg.t1 + 10 < sg.nframes ? sg.t1 + 10 : sg.nframes);
+  const int end = (int)sg.t1 + 10;  // last iteration decides frame t1-1
+  const double* src = A + (uint64_t)sg.gframe0 * row_stride + (loads ? col : 0);
+
+  double hraw[21], hm1[21], pre[PK_PF];
+#pragma unroll
+  for (int u = 0; u < 21; ++u) { hraw[u] = NEG; hm1[u] = NEG; }
+#pragma unroll
+  for (int p = 0; p < PK_PF; ++p) {
+    const int t = lo + p;
+    pre[p] = (loads && t < hi) ? src[(uint64_t)t * row_stride] : NEG;
+  }
+  for (int tb = lo; tb < end; tb += 21) {
+#pragma unroll
+    for (int u = 0; u < 21; ++u) {
+      const int t = tb + u;
+      if (t >= end) break;
+      const double v = pre[u % PK_PF];
+      {
+        const int tn = t + PK_PF;
+        pre[u % PK_PF] = (loads && tn < hi) ? src[(uint64_t)tn * row_stride] : NEG;
+      }
+      double* r = row[t & 1];
+      if (j < PK_COLS) r[li] = v;
+      __syncthreads();
+      double m1 = NEG;
+      if (j < PK_SW) {
+#pragma unroll
+        for (int d = 0; d < 21; ++d) m1 = fmax(m1, r[j + d]);  // columns li-10 .. li+10
+      }
+      hraw[u] = v;
+      hm1[u] = m1;
+      double m2 = hm1[0];
+#pragma unroll
+      for (int q = 1; q < 21; ++q) m2 = fmax(m2, hm1[q]);
+      const double cval = hraw[(u + 11) % 21];  // frame t - 10
+      const int tc = t - 10;
+      const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
+      const bool pk = is_out && in_seg && (cval == m2) && (cval > amp_min);
+      const unsigned long long bal = __ballot(pk);
+      if (in_seg && lane == 0)
+        mask[((uint64_t)(sg.gframe0 + tc) * n_slabs + slab) * 4 + wave] = bal;
+    }
+  }
+}
+
+// K3: expand peak masks into the ordered peak list.  One thread per mask word.
+__global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __restrict__ mask,
+                                                          const uint32_t* __restrict__ word_off, uint64_t n_words,
+                                                          uint32_t n_slabs, const uint32_t* __restrict__ clip_foff,
+                                                          uint32_t n_clips, uint16_t* __restrict__ peak_f,
+                                                          uint32_t* __restrict__ peak_t) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t m = mask[w];
+  if (!m) return;
+  const uint32_t per_frame = n_slabs * 4;
+  const uint32_t g = (uint32_t)(w / per_frame);
+  const uint32_t rem = (uint32_t)(w % per_frame);
+  const uint32_t slab = rem >> 2, wv = rem & 3;
+  uint32_t lo = 0, hi = n_clips;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (clip_foff[mid] <= g) lo = mid; else hi = mid;
+  }
+  const uint32_t t = g - clip_foff[lo];
+  uint32_t o = word_off[w];
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    peak_f[o] = (uint16_t)(slab * PK_SW + wv * 64 + b);
+    peak_t[o] = t;
+    ++o;
+  }
+}
+
+// per-clip CSR offsets from a per-element exclusive scan: out[c] = scan[first[c]*mult] (or total at the end)
+__global__ void gather_offsets_kernel(const uint32_t* __restrict__ scan, const uint64_t* __restrict__ total,
+                                      const uint32_t* __restrict__ first, uint64_t mult, uint64_t n_elems,
+                                      uint32_t n_clips, uint32_t* __restrict__ out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_clips) return;
+  const uint64_t idx = (uint64_t)first[c] * mult;
+  out[c] = (c == n_clips || idx >= n_elems) ? (uint32_t)*total : scan[idx];
+}
+
+// K4a: number of valid partners of each peak (prefix of the next fan-1 peaks of the same clip with dt <= 200)
+__global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t* __restrict__ peak_t,
+                                                         const uint32_t* __restrict__ peak_coff, uint32_t n_clips,
+                                                         uint32_t n_peaks, uint32_t fan, uint32_t* __restrict__ cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_peaks) return;
+  uint32_t lo = 0, hi = n_clips;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (peak_coff[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint32_t endp = peak_coff[lo + 1];
+  const uint32_t t1 = peak_t[i];
+  uint32_t c = 0;
+  for (uint32_t jn = 1; jn < fan; ++jn) {
+    if (i + jn >= endp) break;
+    const uint32_t dt = peak_t[i + jn] - t1;  // sorted by time: dt >= 0 = MIN_HASH_TIME_DELTA
+    if (dt <= SHZ_MAX_DT) ++c;
+  }
+  cnt[i] = c;
+}
+
+// K4b: write (key32, t1) in (i, j) generation order
+__global__ __launch_bounds__(256) void pair_write_kernel(const uint16_t* __restrict__ peak_f,
+                                                         const uint32_t* __restrict__ peak_t,
+                                                         const uint32_t* __restrict__ peak_coff, uint32_t n_clips,
+                                                         uint32_t n_peaks, uint32_t fan,
+                                                         const uint32_t* __restrict__ hoff, uint32_t* __restrict__ key32,
+                                                         uint32_t* __restrict__ t1out, uint64_t out_base, uint64_t cap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_peaks) return;
+  uint32_t lo = 0, hi = n_clips;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (peak_coff[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint32_t endp = peak_coff[lo + 1];
+  const uint32_t t1 = peak_t[i], f1 = peak_f[i];
+  uint64_t o = out_base + hoff[i];
+  for (uint32_t jn = 1; jn < fan; ++jn) {
+    if (i + jn >= endp) break;
+    const uint32_t dt = peak_t[i + jn] - t1;
+    if (dt <= SHZ_MAX_DT) {
+      if (o < cap) {
+        key32[o] = (f1 << 20) | ((uint32_t)peak_f[i + jn] << 8) | dt;
+        t1out[o] = t1;
+      }
+      ++o;
+    }
+  }
+}
+
+// transpose [F][stride] (frame-major) -> [n_bins][F] (the reference's freq-major layout)
+__global__ void transpose_db_kernel(const double* __restrict__ in, uint32_t stride, uint32_t F, uint32_t n_bins,
+                                    double* __restrict__ out) {
+  __shared__ double tile[32][33];
+  const uint32_t bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: bins, by: frames
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    uint32_t f = by + r, b = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (f < F && b < n_bins) ? in[(uint64_t)f * stride + b] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    uint32_t b = bx + r, f = by + threadIdx.x;
+    if (b < n_bins && f < F) out[(uint64_t)b * F + f] = tile[threadIdx.x][r];
+  }
+}
+
+// transpose back: [n_rows][n_cols] freq-major host layout -> [n_cols][stride] frame-major
+__global__ void transpose_in_kernel(const double* __restrict__ in, uint32_t n_rows, uint32_t n_cols, uint32_t stride,
+                                    double* __restrict__ out) {
+  __shared__ double tile[32][33];
+  const uint32_t bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: cols(time), by: rows(freq)
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    uint32_t rr = by + r, cc = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (rr < n_rows && cc < n_cols) ? in[(uint64_t)rr * n_cols + cc] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    uint32_t cc = bx + r, rr = by + threadIdx.x;
+    if (cc < n_cols && rr < n_rows) out[(uint64_t)cc * stride + rr] = tile[threadIdx.x][r];
+  }
+}
+
+// ======================================================================================
+// host orchestration
+// ======================================================================================
+extern "C" uint32_t shz_frame_count(uint64_t n) {
+  if (n < SHZ_NFFT) return 1;
+  return (uint32_t)((n - SHZ_NFFT) / SHZ_HOP + 1);
+}
+
+#define PK_SEG 128  // output frames per peak_pick workgroup
+
+struct sub_batch {
+  uint32_t c0, c1;        // clips [c0, c1)
+  uint32_t frames;
+};
+
+static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t n_clips,
+                                std::vector<sub_batch>& out) {
+  uint64_t max_frames = ctx->ws_limit / ((uint64_t)DB_STRIDE * 8);
+  if (max_frames > (1u << 19)) max_frames = 1u << 19;  // keeps every per-sub-batch count < 2^32
+  if (max_frames < 64) max_frames = 64;
+  sub_batch cur{0, 0, 0};
+  for (uint32_t c = 0; c < n_clips; ++c) {
+    if (clip_off[c + 1] < clip_off[c]) SHZ_FAIL(ctx, SHZ_E_INVALID, "clip_off must be non-decreasing (clip %u)", c);
+    uint64_t f = shz_frame_count(clip_off[c + 1] - clip_off[c]);
+    if (f > max_frames)
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "clip %u has %llu frames; at most %llu fit the workspace limit", c,
+               (unsigned long long)f, (unsigned long long)max_frames);
+    if (cur.frames + f > max_frames && cur.c1 > cur.c0) {
+      out.push_back(cur);
+      cur = sub_batch{c, c, 0};
+    }
+    cur.c1 = c + 1;
+    cur.frames += (uint32_t)f;
+  }
+  if (cur.c1 > cur.c0) out.push_back(cur);
+  return SHZ_OK;
+}
+
+struct sub_dev {
+  const int16_t* pcm;     // device pointer to sample clip_off[c0]... (base such that soff are relative)
+  uint64_t* d_soff;
+  uint64_t* d_len;
+  uint32_t* d_foff;
+  peak_seg* d_segs;
+  uint32_t n_segs;
+  std::vector<uint32_t> foff;
+};
+
+// upload per-clip metadata of a sub-batch; pcm_base_off = sample offset of d_pcm[0] in clip_off units
+static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_batch& sb, uint64_t pcm_base_off,
+                           sub_dev& sd) {
+  const uint32_t nc = sb.c1 - sb.c0;
+  std::vector<uint64_t> soff(nc), len(nc);
+  sd.foff.assign(nc + 1, 0);
+  std::vector<peak_seg> segs;
+  for (uint32_t i = 0; i < nc; ++i) {
+    const uint32_t c = sb.c0 + i;
+    soff[i] = clip_off[c] - pcm_base_off;
+    len[i] = clip_off[c + 1] - clip_off[c];
+    const uint32_t f = shz_frame_count(len[i]);
+    sd.foff[i + 1] = sd.foff[i] + f;
+    for (uint32_t t0 = 0; t0 < f; t0 += PK_SEG)
+      segs.push_back(peak_seg{sd.foff[i], f, t0, std::min(t0 + PK_SEG, f)});
+  }
+  void *p0, *p1;
+  const uint64_t meta_bytes = (uint64_t)nc * 16 + (uint64_t)(nc + 1) * 4 + 64;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, meta_bytes, &p0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META2, segs.size() * sizeof(peak_seg) + 64, &p1));
+  sd.d_soff = (uint64_t*)p0;
+  sd.d_len = sd.d_soff + nc;
+  sd.d_foff = (uint32_t*)(sd.d_len + nc);
+  sd.d_segs = (peak_seg*)p1;
+  sd.n_segs = (uint32_t)segs.size();
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_soff, soff.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_len, len.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_foff, sd.foff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice,
+                              ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  return SHZ_OK;
+}
+
+// PCM of the sub-batch on the device: either the caller's device buffer or a staged copy
+static int32_t stage_pcm(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, const sub_batch& sb,
+                         uint32_t flags, const int16_t** d_pcm, uint64_t* base_off) {
+  const uint64_t s0 = clip_off[sb.c0], s1 = clip_off[sb.c1];
+  if (flags & SHZ_PCM_DEVICE) {
+    *d_pcm = pcm;
+    *base_off = 0;
+    return SHZ_OK;
+  }
+  void* p;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PCM, (s1 - s0) * 2 + 64, &p));
+  if (s1 > s0) SHZ_HIP(ctx, hipMemcpyAsync(p, pcm + s0, (s1 - s0) * 2, hipMemcpyHostToDevice, ctx->stream));
+  *d_pcm = (const int16_t*)p;
+  *base_off = s0;
+  return SHZ_OK;
+}
+
+static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd, uint32_t nc, uint32_t frames,
+                           uint32_t fs, double* d_db) {
+  shz_prof_scope ps(ctx, 0);
+  stft_args a;
+  a.pcm = d_pcm;
+  a.clip_soff = sd.d_soff;
+  a.clip_len = sd.d_len;
+  a.clip_foff = sd.d_foff;
+  a.n_clips = nc;
+  a.total_frames = frames;
+  a.out = d_db;
+  a.window = ctx->d_window;
+  a.tw = ctx->d_twiddle;
+  a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
+  uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * 3;
+  if (grid > frames) grid = frames;
+  hipLaunchKernelGGL(stft_psd_db_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}
+
+// peaks of a frame-major dB buffer -> device peak list (ws PEAK_F / PEAK_T) + per-clip offsets (ws PEAK_CLIP)
+static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, uint32_t n_bins, const sub_dev& sd,
+                         uint32_t nc, uint32_t frames, double amp_min, uint16_t** d_pf, uint32_t** d_pt,
+                         uint32_t** d_pcoff, uint32_t* n_peaks) {
+  const uint32_t n_slabs = (n_bins + PK_SW - 1) / PK_SW;
+  const uint64_t n_words = (uint64_t)frames * n_slabs * 4;
+  void *d_mask, *d_woff, *d_tot;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MASK, n_words * 8, &d_mask));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, n_words * 4, &d_woff));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &d_tot));
+  {
+    shz_prof_scope ps(ctx, 1);
+    hipLaunchKernelGGL(peak_pick_kernel, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride, n_bins,
+                       sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
+    SHZ_HIP(ctx, hipGetLastError());
+  }
+  uint64_t tot = 0;
+  {
+    shz_prof_scope ps(ctx, 2);
+    SHZ_TRY(shz_scan_popc64(ctx, (const uint64_t*)d_mask, (uint32_t*)d_woff, n_words, (uint64_t*)d_tot));
+    SHZ_HIP(ctx, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void *pf, *pt, *pc;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, tot * 2 + 64, &pf));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, tot * 4 + 64, &pt));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(nc + 1) * 4 + 64, &pc));
+    if (n_words) {
+      hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const uint64_t*)d_mask, (const uint32_t*)d_woff, n_words, n_slabs, sd.d_foff, nc,
+                         (uint16_t*)pf, (uint32_t*)pt);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_woff, (const uint64_t*)d_tot, sd.d_foff, (uint64_t)n_slabs * 4, n_words, nc,
+                       (uint32_t*)pc);
+    SHZ_HIP(ctx, hipGetLastError());
+    *d_pf = (uint16_t*)pf;
+    *d_pt = (uint32_t*)pt;
+    *d_pcoff = (uint32_t*)pc;
+  }
+  *n_peaks = (uint32_t)tot;
+  return SHZ_OK;
+}
+
+// pair hashing of a device peak list; writes into (d_key, d_t1) at out_base (device arrays of capacity cap)
+static int32_t run_pairs(shz_ctx* ctx, const uint16_t* d_pf, const uint32_t* d_pt, const uint32_t* d_pcoff, uint32_t nc,
+                         uint32_t n_peaks, uint32_t fan, uint32_t* d_key, uint32_t* d_t1, uint64_t out_base, uint64_t cap,
+                         uint64_t* n_hashes, std::vector<uint32_t>* clip_hoff /* nc+1, relative */) {
+  shz_prof_scope ps(ctx, 3);
+  void *d_cnt, *d_hoff, *d_tot, *d_choff;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)n_peaks * 4 + 64, &d_cnt));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)n_peaks * 4 + 64, &d_hoff));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &d_tot));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)(nc + 1) * 4 + 64, &d_choff));
+  const unsigned nb = (n_peaks + 255) / 256;
+  if (n_peaks) {
+    hipLaunchKernelGGL(pair_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pt, d_pcoff, nc, n_peaks, fan,
+                       (uint32_t*)d_cnt);
+    SHZ_HIP(ctx, hipGetLastError());
+  }
+  SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)d_cnt, (uint32_t*)d_hoff, n_peaks, (uint64_t*)d_tot));
+  if (n_peaks) {
+    hipLaunchKernelGGL(pair_write_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pf, d_pt, d_pcoff, nc, n_peaks, fan,
+                       (const uint32_t*)d_hoff, d_key, d_t1, out_base, cap);
+    SHZ_HIP(ctx, hipGetLastError());
+  }
+  // per-clip hash offsets: hoff[pcoff[c]]
+  hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)d_hoff, (const uint64_t*)d_tot, d_pcoff, (uint64_t)1, (uint64_t)n_peaks, nc,
+                     (uint32_t*)d_choff);
+  SHZ_HIP(ctx, hipGetLastError());
+  uint64_t tot = 0;
+  clip_hoff->resize(nc + 1);
+  SHZ_HIP(ctx, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(clip_hoff->data(), d_choff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_hashes = tot;
+  return SHZ_OK;
+}
+
+static int32_t check_common(shz_ctx* ctx, const void* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (!clip_off) SHZ_FAIL(ctx, SHZ_E_INVALID, "clip_off is NULL");
+  if (fs == 0) SHZ_FAIL(ctx, SHZ_E_INVALID, "Fs must be > 0");
+  if (n_clips && !pcm && clip_off[n_clips] > clip_off[0]) SHZ_FAIL(ctx, SHZ_E_INVALID, "pcm is NULL");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
+                               uint32_t fs, uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* count) {
+  SHZ_TRY(check_common(ctx, pcm, clip_off, n_clips, fs));
+  uint64_t need = 0;
+  for (uint32_t c = 0; c < n_clips; ++c) need += (uint64_t)shz_frame_count(clip_off[c + 1] - clip_off[c]) * SHZ_NBINS;
+  if (count) *count = need;
+  if (need > cap_doubles || (need && !out_db)) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_stft_db: need %llu doubles", (unsigned long long)need);
+  std::vector<sub_batch> subs;
+  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, subs));
+  uint64_t out_pos = 0;
+  for (const sub_batch& sb : subs) {
+    const uint32_t nc = sb.c1 - sb.c0;
+    const int16_t* d_pcm;
+    uint64_t base;
+    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
+    sub_dev sd;
+    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, sd));
+    void *d_db, *d_tr;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * DB_STRIDE * 8, &d_db));
+    SHZ_TRY(launch_stft(ctx, d_pcm, sd, nc, sb.frames, fs, (double*)d_db));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)sb.frames * SHZ_NBINS * 8, &d_tr));
+    uint64_t tr_pos = 0;
+    for (uint32_t i = 0; i < nc; ++i) {
+      const uint32_t F = sd.foff[i + 1] - sd.foff[i];
+      dim3 grid((SHZ_NBINS + 31) / 32, (F + 31) / 32);
+      hipLaunchKernelGGL(transpose_db_kernel, grid, dim3(32, 8), 0, ctx->stream,
+                         (const double*)d_db + (uint64_t)sd.foff[i] * DB_STRIDE, (uint32_t)DB_STRIDE, F,
+                         (uint32_t)SHZ_NBINS, (double*)d_tr + tr_pos);
+      tr_pos += (uint64_t)F * SHZ_NBINS;
+    }
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_HIP(ctx, hipMemcpyAsync(out_db + out_pos, d_tr, tr_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out_pos += tr_pos;
+  }
+  return SHZ_OK;
+}
+
+// shared driver for shz_peaks / shz_fingerprint_batch
+static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
+                              double amp_min, uint32_t fan, uint32_t flags, bool want_hashes,
+                              // peaks outputs
+                              uint16_t* peak_f, uint32_t* peak_t, uint64_t* peak_off,
+                              // hash outputs
+                              uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count) {
+  SHZ_TRY(check_common(ctx, pcm, clip_off, n_clips, fs));
+  if (want_hashes && (fan < 1 || fan > 64)) SHZ_FAIL(ctx, SHZ_E_INVALID, "fan_value must be in [1,64]");
+  std::vector<sub_batch> subs;
+  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, subs));
+  const bool out_dev = (flags & SHZ_OUT_DEVICE) != 0;
+  uint64_t total = 0;  // peaks or hashes emitted so far
+  if (want_hashes ? (hash_off != nullptr) : (peak_off != nullptr)) (want_hashes ? hash_off : peak_off)[0] = 0;
+  for (const sub_batch& sb : subs) {
+    const uint32_t nc = sb.c1 - sb.c0;
+    const int16_t* d_pcm;
+    uint64_t base;
+    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
+    sub_dev sd;
+    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, sd));
+    void* d_db;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * DB_STRIDE * 8, &d_db));
+    SHZ_TRY(launch_stft(ctx, d_pcm, sd, nc, sb.frames, fs, (double*)d_db));
+    uint16_t* d_pf;
+    uint32_t *d_pt, *d_pcoff, n_peaks;
+    SHZ_TRY(run_peaks(ctx, (const double*)d_db, DB_STRIDE, SHZ_NBINS, sd, nc, sb.frames, amp_min, &d_pf, &d_pt,
+                      &d_pcoff, &n_peaks));
+    if (!want_hashes) {
+      std::vector<uint32_t> pco(nc + 1);
+      SHZ_HIP(ctx, hipMemcpyAsync(pco.data(), d_pcoff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (peak_off)
+        for (uint32_t i = 0; i < nc; ++i) peak_off[sb.c0 + i + 1] = total + pco[i + 1];
+      if (total + n_peaks <= cap && n_peaks) {
+        const hipMemcpyKind kd = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        SHZ_HIP(ctx, hipMemcpyAsync(peak_f + total, d_pf, (uint64_t)n_peaks * 2, kd, ctx->stream));
+        SHZ_HIP(ctx, hipMemcpyAsync(peak_t + total, d_pt, (uint64_t)n_peaks * 4, kd, ctx->stream));
+        SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
+      total += n_peaks;
+      continue;
+    }
+    // hashes: write straight into the caller's device arrays, or into a staging pair for host output
+    uint32_t *d_key, *d_t1;
+    uint64_t out_base, dcap;
+    if (out_dev) {
+      d_key = key32;
+      d_t1 = t1;
+      out_base = total;
+      dcap = cap;
+    } else {
+      void *pk, *pt1;
+      const uint64_t upper = (uint64_t)n_peaks * (fan > 1 ? fan - 1 : 0);
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, upper * 4 + 64, &pk));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, upper * 4 + 64, &pt1));
+      d_key = (uint32_t*)pk;
+      d_t1 = (uint32_t*)pt1;
+      out_base = 0;
+      dcap = upper;
+    }
+    uint64_t n_h = 0;
+    std::vector<uint32_t> choff;
+    SHZ_TRY(run_pairs(ctx, d_pf, d_pt, d_pcoff, nc, n_peaks, fan, d_key, d_t1, out_base, dcap, &n_h, &choff));
+    if (hash_off)
+      for (uint32_t i = 0; i < nc; ++i) hash_off[sb.c0 + i + 1] = total + choff[i + 1];
+    if (!out_dev && total + n_h <= cap && n_h) {
+      SHZ_HIP(ctx, hipMemcpyAsync(key32 + total, d_key, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipMemcpyAsync(t1 + total, d_t1, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    total += n_h;
+  }
+  if (count) *count = total;
+  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)total,
+                            (unsigned long long)cap);
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_peaks(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
+                             double amp_min, uint32_t flags, uint16_t* peak_f, uint32_t* peak_t, uint64_t* peak_off,
+                             uint64_t cap, uint64_t* count) {
+  return extract_driver(ctx, pcm, clip_off, n_clips, fs, amp_min, 0, flags, false, peak_f, peak_t, peak_off, nullptr,
+                        nullptr, nullptr, cap, count);
+}
+
+extern "C" int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
+                                         uint32_t fs, double amp_min, uint32_t fan_value, uint32_t flags,
+                                         uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap,
+                                         uint64_t* count) {
+  return extract_driver(ctx, pcm, clip_off, n_clips, fs, amp_min, fan_value, flags, true, nullptr, nullptr, nullptr,
+                        key32, t1, hash_off, cap, count);
+}
+
+extern "C" int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t n_rows, uint32_t n_cols,
+                                     double amp_min, uint32_t* out_f, uint32_t* out_t, uint64_t cap, uint64_t* count) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (count) *count = 0;
+  if (n_rows == 0 || n_cols == 0) return SHZ_OK;
+  if (!arr2d) SHZ_FAIL(ctx, SHZ_E_INVALID, "arr2d is NULL");
+  if (n_rows > 65535) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "at most 65535 rows (frequency bins)");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t stride = (n_rows + 7) & ~7u;
+  void *d_in, *d_db;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)n_rows * n_cols * 8, &d_in));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)n_cols * stride * 8, &d_db));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_in, arr2d, (uint64_t)n_rows * n_cols * 8, hipMemcpyHostToDevice, ctx->stream));
+  dim3 grid((n_cols + 31) / 32, (n_rows + 31) / 32);
+  hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(32, 8), 0, ctx->stream, (const double*)d_in, n_rows, n_cols, stride,
+                     (double*)d_db);
+  SHZ_HIP(ctx, hipGetLastError());
+  // one "clip" of n_cols frames
+  sub_dev sd;
+  std::vector<peak_seg> segs;
+  for (uint32_t t0 = 0; t0 < n_cols; t0 += PK_SEG) segs.push_back(peak_seg{0, n_cols, t0, std::min(t0 + PK_SEG, n_cols)});
+  void *p0, *p1;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, 64, &p0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META2, segs.size() * sizeof(peak_seg) + 64, &p1));
+  uint32_t foff[2] = {0, n_cols};
+  sd.d_foff = (uint32_t*)p0;
+  sd.d_segs = (peak_seg*)p1;
+  sd.n_segs = (uint32_t)segs.size();
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_foff, foff, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint16_t* d_pf;
+  uint32_t *d_pt, *d_pcoff, n_peaks;
+  SHZ_TRY(run_peaks(ctx, (const double*)d_db, stride, n_rows, sd, 1, n_cols, amp_min, &d_pf, &d_pt, &d_pcoff, &n_peaks));
+  if (count) *count = n_peaks;
+  if (n_peaks > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %u peaks", n_peaks);
+  if (!n_peaks) return SHZ_OK;
+  std::vector<uint16_t> pf(n_peaks);
+  std::vector<uint32_t> pt(n_peaks), idx(n_peaks);
+  SHZ_HIP(ctx, hipMemcpyAsync(pf.data(), d_pf, (uint64_t)n_peaks * 2, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(pt.data(), d_pt, (uint64_t)n_peaks * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // device order is (t asc, f asc); np.where order is (f asc, t asc): stable re-sort by f
+  for (uint32_t i = 0; i < n_peaks; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return pf[a] < pf[b]; });
+  for (uint32_t i = 0; i < n_peaks; ++i) {
+    out_f[i] = pf[idx[i]];
+    out_t[i] = pt[idx[i]];
+  }
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_pair_hash(shz_ctx* ctx, const uint16_t* peak_f, const uint32_t* peak_t, const uint64_t* peak_off,
+                                 uint32_t n_clips, uint32_t fan_value, uint32_t* key32, uint32_t* t1, uint64_t* hash_off,
+                                 uint64_t cap, uint64_t* count) {
+  if (!ctx || !peak_off) return SHZ_E_INVALID;
+  if (fan_value < 1 || fan_value > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "fan_value must be in [1,64]");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t n = peak_off[n_clips] - peak_off[0];
+  if (n >= (1ull << 30)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "too many peaks in one call");
+  if (hash_off) hash_off[0] = 0;
+  if (count) *count = 0;
+  if (n_clips == 0) return SHZ_OK;
+  std::vector<uint32_t> pco(n_clips + 1);
+  for (uint32_t c = 0; c <= n_clips; ++c) pco[c] = (uint32_t)(peak_off[c] - peak_off[0]);
+  void *pf, *pt, *pc, *pk, *pt1;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, n * 2 + 64, &pf));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, n * 4 + 64, &pt));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(n_clips + 1) * 4 + 64, &pc));
+  const uint64_t upper = n * (fan_value - 1);
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, upper * 4 + 64, &pk));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, upper * 4 + 64, &pt1));
+  if (n) {
+    SHZ_HIP(ctx, hipMemcpyAsync(pf, peak_f + peak_off[0], n * 2, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(pt, peak_t + peak_off[0], n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SHZ_HIP(ctx, hipMemcpyAsync(pc, pco.data(), (uint64_t)(n_clips + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t n_h = 0;
+  std::vector<uint32_t> choff;
+  SHZ_TRY(run_pairs(ctx, (const uint16_t*)pf, (const uint32_t*)pt, (const uint32_t*)pc, n_clips, (uint32_t)n, fan_value,
+                    (uint32_t*)pk, (uint32_t*)pt1, 0, upper, &n_h, &choff));
+  if (hash_off)
+    for (uint32_t c = 0; c < n_clips; ++c) hash_off[c + 1] = choff[c + 1];
+  if (count) *count = n_h;
+  if (n_h > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu hashes", (unsigned long long)n_h);
+  if (n_h) {
+    SHZ_HIP(ctx, hipMemcpyAsync(key32, pk, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(t1, pt1, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SHZ_OK;
+}

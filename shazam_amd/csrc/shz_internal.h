@@ -1,0 +1,129 @@
+// Internal declarations shared by the libshz.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/shz.h"
+
+#define SHZ_FAIL(ctx, code, ...)                                   \
+  do {                                                             \
+    char _b[512];                                                  \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);                         \
+    (ctx)->err = _b;                                               \
+    return (code);                                                 \
+  } while (0)
+
+#define SHZ_HIP(ctx, call)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (call);                                                                      \
+    if (_e != hipSuccess) SHZ_FAIL(ctx, SHZ_E_HIP, "%s failed: %s (%s:%d)", #call,                \
+                                   hipGetErrorString(_e), __FILE__, __LINE__);                   \
+  } while (0)
+
+#define SHZ_TRY(expr)                  \
+  do {                                 \
+    int32_t _s = (expr);               \
+    if (_s != SHZ_OK) return _s;       \
+  } while (0)
+
+// a growable device buffer owned by the ctx (scratch arena slot)
+struct shz_buf {
+  void* p = nullptr;
+  uint64_t cap = 0;
+};
+
+enum {
+  SHZ_WS_DB = 0,     // dB spectrogram [frames][row_stride] f64
+  SHZ_WS_MASK,       // peak bit masks
+  SHZ_WS_SCAN,       // scan outputs
+  SHZ_WS_SCAN_TMP,   // scan block sums
+  SHZ_WS_PEAK_F,
+  SHZ_WS_PEAK_T,
+  SHZ_WS_PEAK_CLIP,
+  SHZ_WS_HCNT,
+  SHZ_WS_HOFF,
+  SHZ_WS_META,       // per-clip metadata (frame offsets, sample offsets)
+  SHZ_WS_META2,
+  SHZ_WS_PCM,        // staged host PCM
+  SHZ_WS_KEY,
+  SHZ_WS_T1,
+  SHZ_WS_MISC0,
+  SHZ_WS_MISC1,
+  SHZ_WS_MISC2,
+  SHZ_WS_MISC3,
+  SHZ_WS_SORT_A,
+  SHZ_WS_SORT_B,
+  SHZ_WS_SORT_C,
+  SHZ_WS_SORT_D,
+  SHZ_WS_SORT_H,
+  SHZ_WS_M0, SHZ_WS_M1, SHZ_WS_M2, SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7,
+  SHZ_WS_COUNT
+};
+
+struct shz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+  uint64_t ws_limit = 0;
+  shz_buf ws[SHZ_WS_COUNT];
+  // constant tables (device)
+  double* d_window = nullptr;   // hann(4096)
+  double2* d_twiddle = nullptr; // W4096^k, k in [0,1024]
+  int16_t* d_sine_lut = nullptr;
+  double win_sumsq = 0.0;
+  // timers / profiling
+  hipEvent_t tev[16][2];
+  bool tev_init = false;
+  bool profiling = false;
+  float kernel_ms[8] = {0};
+  uint32_t kernel_launches[8] = {0};
+  hipEvent_t pev[2] = {nullptr, nullptr};
+  // match stats
+  uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
+};
+
+// ensure ws slot has >= bytes (grow-only; contents not preserved)
+int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out);
+
+// profiling helpers: bracket a kernel group with events when ctx->profiling
+struct shz_prof_scope {
+  shz_ctx* c;
+  int which;
+  shz_prof_scope(shz_ctx* ctx, int w) : c(ctx), which(w) {
+    if (c->profiling) (void)hipEventRecord(c->pev[0], c->stream);
+  }
+  ~shz_prof_scope() {
+    if (c->profiling) {
+      (void)hipEventRecord(c->pev[1], c->stream);
+      (void)hipEventSynchronize(c->pev[1]);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, c->pev[0], c->pev[1]);
+      c->kernel_ms[which] += ms;
+      c->kernel_launches[which] += 1;
+    }
+  }
+};
+
+// ---- device primitives (shz_prims.hip) ------------------------------------------------
+// exclusive scan of n u32 values -> u32 (total written to d_total if non-null, as u64)
+int32_t shz_scan_u32(shz_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* d_total);
+// exclusive scan of popcount(mask[i]) for u64 words
+int32_t shz_scan_popc64(shz_ctx* ctx, const uint64_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* d_total);
+// exclusive scan of n u64 values -> u64
+int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_total);
+// stable LSD radix sort of u64 keys (bits [bit_lo, bit_hi)) with an optional 4- or 8-byte payload.
+// keys/vals are ping-ponged between (k0,v0) and (k1,v1); *out_sel tells which pair holds the result.
+int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, uint64_t n,
+                     int bit_lo, int bit_hi, int* out_sel);
+
+// ---- RCCL helpers (shz_comm.hip) ----------------------------------------------------------
+int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks);
+int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes);
+int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
+                                  const uint64_t* displ);

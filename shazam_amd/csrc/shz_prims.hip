@@ -1,0 +1,264 @@
+// Device-wide primitives used by the extraction and match paths: exclusive scans and a
+// stable LSD radix sort.  Wave = 64 lanes; blocks of 256 threads (4 waves).
+#include "shz_internal.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+struct in_u32 {
+  const uint32_t* p;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return p[i]; }
+};
+struct in_popc64 {
+  const uint64_t* p;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popcll(p[i]); }
+};
+struct in_u64 {
+  const uint64_t* p;
+  __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan across the block of one value per thread; returns exclusive prefix, *total = block sum
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T* total, T* lds /* >= 5 entries */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T inc = wave_incl_scan(v, lane);
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  T woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    T s = lds[w];
+    if (w < wave) woff += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return woff + inc - v;
+}
+
+template <typename T, typename In>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(In in, T* __restrict__ sums, uint64_t n) {
+  __shared__ T lds[8];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += (T)in(base + i);
+  T tot;
+  block_excl_scan(s, &tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+template <typename T, typename In>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(In in, T* __restrict__ out,
+                                                                   const T* __restrict__ block_off, uint64_t n,
+                                                                   uint64_t* __restrict__ total) {
+  __shared__ T lds[8];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  T v[SCAN_ITEMS];
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? (T)in(base + i) : (T)0;
+    s += v[i];
+  }
+  T tot;
+  T off = block_excl_scan(s, &tot, lds) + (block_off ? block_off[blockIdx.x] : (T)0);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = off;
+    off += v[i];
+  }
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = (uint64_t)off;
+}
+
+__global__ void set_u64_kernel(uint64_t* p, uint64_t v) { *p = v; }
+
+template <typename T, typename In>
+static int32_t scan_impl(shz_ctx* ctx, In in, T* d_out, uint64_t n, uint64_t* d_total, T* tmp, uint64_t tmp_elems) {
+  if (n == 0) {
+    if (d_total) hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, ctx->stream, d_total, 0ull);
+    return SHZ_OK;
+  }
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 1) {
+    hipLaunchKernelGGL((scan_apply_kernel<T, In>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, d_out,
+                       (const T*)nullptr, n, d_total);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
+  }
+  if (nb > tmp_elems) SHZ_FAIL(ctx, SHZ_E_INVALID, "scan: temp too small");
+  hipLaunchKernelGGL((scan_sums_kernel<T, In>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, tmp, n);
+  SHZ_HIP(ctx, hipGetLastError());
+  // scan the block sums in place (recursive), using the tail of tmp as the next level's scratch
+  if (sizeof(T) == 4) {
+    in_u32 nin{(const uint32_t*)tmp};
+    SHZ_TRY((scan_impl<uint32_t, in_u32>(ctx, nin, (uint32_t*)tmp, nb, nullptr, (uint32_t*)tmp + nb, tmp_elems - nb)));
+  } else {
+    in_u64 nin{(const uint64_t*)tmp};
+    SHZ_TRY((scan_impl<uint64_t, in_u64>(ctx, nin, (uint64_t*)tmp, nb, nullptr, (uint64_t*)tmp + nb, tmp_elems - nb)));
+  }
+  hipLaunchKernelGGL((scan_apply_kernel<T, In>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, d_out,
+                     (const T*)tmp, n, d_total);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}
+
+static uint64_t scan_tmp_elems(uint64_t n) {
+  uint64_t t = 0;
+  while (n > SCAN_TILE) {
+    n = (n + SCAN_TILE - 1) / SCAN_TILE;
+    t += n;
+  }
+  return t + 16;
+}
+
+int32_t shz_scan_u32(shz_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* d_total) {
+  if (n >= (1ull << 41)) SHZ_FAIL(ctx, SHZ_E_INVALID, "scan too large");
+  uint64_t te = scan_tmp_elems(n);
+  void* tmp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN_TMP, te * 8, &tmp));
+  return scan_impl<uint32_t, in_u32>(ctx, in_u32{d_in}, d_out, n, d_total, (uint32_t*)tmp, te);
+}
+
+int32_t shz_scan_popc64(shz_ctx* ctx, const uint64_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* d_total) {
+  uint64_t te = scan_tmp_elems(n);
+  void* tmp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN_TMP, te * 8, &tmp));
+  return scan_impl<uint32_t, in_popc64>(ctx, in_popc64{d_in}, d_out, n, d_total, (uint32_t*)tmp, te);
+}
+
+int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_total) {
+  uint64_t te = scan_tmp_elems(n);
+  void* tmp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN_TMP, te * 8, &tmp));
+  return scan_impl<uint64_t, in_u64>(ctx, in_u64{d_in}, d_out, n, d_total, (uint64_t*)tmp, te);
+}
+
+// ---------------------------------------------------------------------------------------
+// Stable LSD radix sort, 8 bits per pass.  Tile = 256 threads x 16 rounds; round r of a block
+// covers elements [tile + r*256, tile + r*256 + 256) so the in-tile order is the memory order.
+#define SORT_THREADS 256
+#define SORT_ROUNDS 16
+#define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                                  uint32_t* __restrict__ hist /*[256][nblocks]*/,
+                                                                  uint32_t nblocks) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <int VB> struct val_t { typedef uint32_t type; };
+template <> struct val_t<8> { typedef uint64_t type; };
+
+template <int VB>
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys,
+                                                                     const void* __restrict__ vals_,
+                                                                     uint64_t* __restrict__ okeys,
+                                                                     void* __restrict__ ovals_, uint64_t n, int shift,
+                                                                     const uint32_t* __restrict__ offs /*[256][nblocks]*/,
+                                                                     uint32_t nblocks) {
+  typedef typename val_t<VB>::type V;
+  const V* vals = (const V*)vals_;
+  V* ovals = (V*)ovals_;
+  __shared__ uint32_t running[256];      // global write cursor per digit for this block
+  __shared__ uint32_t cnt[4][256];       // per-wave digit counts of the current round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = offs[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
+    if (base + (uint64_t)r * SORT_THREADS >= n) break;  // uniform
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const bool valid = i < n;
+    uint64_t k = valid ? keys[i] : 0;
+    V v = 0;
+    if (VB != 0 && valid) v = vals[i];
+    const uint32_t d = (uint32_t)(k >> shift) & 255u;
+    // lanes of this wave holding the same digit (invalid lanes form their own class)
+    unsigned long long peers = __ballot(valid);
+    if (!valid) peers = ~peers;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+    if (valid && rank == 0) cnt[wave][d] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    uint32_t pos = 0;
+    if (valid) {
+      pos = running[d] + rank;
+      for (int w = 0; w < wave; ++w) pos += cnt[w][d];
+    }
+    __syncthreads();
+    running[threadIdx.x] += cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+    if (valid) {
+      okeys[pos] = k;
+      if (VB != 0) ovals[pos] = v;
+    }
+    __syncthreads();
+  }
+}
+
+int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, uint64_t n, int bit_lo,
+                     int bit_hi, int* out_sel) {
+  *out_sel = 0;
+  if (n <= 1 || bit_hi <= bit_lo) return SHZ_OK;
+  if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: n must be < 2^32 (got %llu)", (unsigned long long)n);
+  if (vbytes != 0 && vbytes != 4 && vbytes != 8) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: payload must be 0, 4 or 8 bytes");
+  const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+  void* hist;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, (uint64_t)nblocks * 256 * 4, &hist));
+  uint64_t* kin = k0;
+  uint64_t* kout = k1;
+  void* vin = v0;
+  void* vout = v1;
+  int sel = 0;
+  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, n, shift,
+                       (uint32_t*)hist, nblocks);
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, (uint64_t)nblocks * 256, nullptr));
+    if (vbytes == 4)
+      hipLaunchKernelGGL(sort_scatter_kernel<4>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
+                         vout, n, shift, (const uint32_t*)hist, nblocks);
+    else if (vbytes == 8)
+      hipLaunchKernelGGL(sort_scatter_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
+                         vout, n, shift, (const uint32_t*)hist, nblocks);
+    else
+      hipLaunchKernelGGL(sort_scatter_kernel<0>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
+                         vout, n, shift, (const uint32_t*)hist, nblocks);
+    SHZ_HIP(ctx, hipGetLastError());
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    void* tv = vin; vin = vout; vout = tv;
+    sel ^= 1;
+  }
+  *out_sel = sel;
+  return SHZ_OK;
+}

@@ -1,0 +1,863 @@
+// The fingerprint table resident in HBM and the match/align path on it.
+//   table rows (key32, song_id, offset) replace the MySQL `fingerprints` table
+//     (mysql_database.py:46-68: INDEX on hash, UNIQUE(song_id, offset, hash), INSERT IGNORE)
+//   shz_match_batch replaces return_matches + align_matches (recognizer.py:222-338)
+//
+// Layout: three u32 column arrays sorted by (key, sid, off), duplicates removed, plus a bucket
+// index over key >> 8 (first row of every (f1, f2) prefix) so a probe is one index read and a
+// short binary search over dt.
+#include <algorithm>
+
+#include "shz_internal.h"
+
+struct shz_table {
+  shz_ctx* ctx = nullptr;
+  uint32_t *key = nullptr, *sid = nullptr, *off = nullptr;
+  uint64_t n = 0;
+  uint32_t *skey = nullptr, *ssid = nullptr, *soff = nullptr;
+  uint64_t ns = 0, scap = 0;
+  uint32_t* bucket = nullptr;
+  uint64_t nbuckets = 0;  // bucket has nbuckets+1 entries
+  uint32_t max_sid = 0, max_off = 0;
+};
+
+static int bits_for(uint64_t v) {
+  int b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b ? b : 1;
+}
+
+// ---------------------------------------------------------------------------------------- kernels
+__global__ void tbl_expand_clips_kernel(const uint32_t* __restrict__ key32, const uint32_t* __restrict__ t1,
+                                        const uint64_t* __restrict__ hash_off, uint32_t n_clips, uint32_t sid0,
+                                        uint64_t n, uint32_t* __restrict__ okey, uint32_t* __restrict__ osid,
+                                        uint32_t* __restrict__ ooff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = hash_off[0] + i;
+  uint32_t lo = 0, hi = n_clips;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (hash_off[mid] <= h) lo = mid; else hi = mid;
+  }
+  okey[i] = key32[h];
+  ooff[i] = t1[h];
+  osid[i] = sid0 + lo;
+}
+
+__global__ void tbl_compose_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
+                                   const uint32_t* __restrict__ off, uint64_t n, uint64_t dst0, uint64_t* __restrict__ k,
+                                   uint32_t* __restrict__ v, uint32_t* __restrict__ maxes) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t s = 0, o = 0;
+  if (i < n) {
+    s = sid[i];
+    o = off[i];
+    k[dst0 + i] = ((uint64_t)s << 32) | o;
+    v[dst0 + i] = key[i];
+  }
+  // wave max then one atomic per wave
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s = max(s, (uint32_t)__shfl_xor((int)s, d, 64));
+    o = max(o, (uint32_t)__shfl_xor((int)o, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&maxes[0], s);
+    atomicMax(&maxes[1], o);
+  }
+}
+
+__global__ void tbl_swap_kernel(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v, uint64_t n,
+                                uint64_t* __restrict__ k2, uint64_t* __restrict__ v2) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  k2[i] = v[i];
+  v2[i] = k[i];
+}
+
+__global__ void tbl_uniq_flag_kernel(const uint64_t* __restrict__ k, const uint64_t* __restrict__ v, uint64_t n,
+                                     uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || k[i] != k[i - 1] || v[i] != v[i - 1]) ? 1u : 0u;
+}
+
+__global__ void tbl_compact_kernel(const uint64_t* __restrict__ k, const uint64_t* __restrict__ v,
+                                   const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n,
+                                   uint32_t* __restrict__ okey, uint32_t* __restrict__ osid, uint32_t* __restrict__ ooff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t p = pos[i];
+  okey[p] = (uint32_t)k[i];
+  osid[p] = (uint32_t)(v[i] >> 32);
+  ooff[p] = (uint32_t)v[i];
+}
+
+__global__ void tbl_bucket_kernel(const uint32_t* __restrict__ key, uint32_t n, uint64_t nbuckets,
+                                  uint32_t* __restrict__ bucket) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nbuckets) return;
+  const uint64_t target = b << 8;  // first key of the bucket (may exceed 32 bits for b = nbuckets)
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if ((uint64_t)key[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  bucket[b] = lo;
+}
+
+__global__ void tbl_count_sid_kernel(const uint32_t* __restrict__ sid, uint64_t n, uint32_t want,
+                                     unsigned long long* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool hit = i < n && sid[i] == want;
+  const unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
+
+// ---------------------------------------------------------------------------------------- table API
+extern "C" int32_t shz_table_create(shz_ctx* ctx, shz_table** out) {
+  if (!ctx || !out) return SHZ_E_INVALID;
+  shz_table* t = new shz_table();
+  t->ctx = ctx;
+  *out = t;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_destroy(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  void* ps[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+  delete t;
+  return SHZ_OK;
+}
+
+static int32_t stage_reserve(shz_table* t, uint64_t extra) {
+  shz_ctx* ctx = t->ctx;
+  const uint64_t need = t->ns + extra;
+  if (need <= t->scap) return SHZ_OK;
+  uint64_t cap = std::max<uint64_t>(need, t->scap * 2);
+  cap = std::max<uint64_t>(cap, 1024);
+  uint32_t* np[3];
+  for (int i = 0; i < 3; ++i) {
+    hipError_t e = hipMalloc(&np[i], cap * 4);
+    if (e != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "table staging: hipMalloc(%llu) failed", (unsigned long long)(cap * 4));
+  }
+  uint32_t** old[3] = {&t->skey, &t->ssid, &t->soff};
+  for (int i = 0; i < 3; ++i) {
+    if (t->ns) SHZ_HIP(ctx, hipMemcpyAsync(np[i], *old[i], t->ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; ++i) {
+    if (*old[i]) SHZ_HIP(ctx, hipFree(*old[i]));
+    *old[i] = np[i];
+  }
+  t->scap = cap;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_insert(shz_table* t, const uint32_t* key32, const uint32_t* sid, const uint32_t* off,
+                                    uint64_t n, uint32_t flags) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (n == 0) return SHZ_OK;
+  if (!key32 || !sid || !off) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_table_insert: NULL column");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_TRY(stage_reserve(t, n));
+  const hipMemcpyKind kd = (flags & SHZ_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  SHZ_HIP(ctx, hipMemcpyAsync(t->skey + t->ns, key32, n * 4, kd, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(t->ssid + t->ns, sid, n * 4, kd, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(t->soff + t->ns, off, n * 4, kd, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->ns += n;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, const uint32_t* t1,
+                                          const uint64_t* hash_off, uint32_t n_clips, uint32_t sid0, uint32_t flags) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (n_clips == 0) return SHZ_OK;
+  if (!hash_off) SHZ_FAIL(ctx, SHZ_E_INVALID, "hash_off is NULL");
+  const uint64_t n = hash_off[n_clips] - hash_off[0];
+  if (n == 0) return SHZ_OK;
+  if (!key32 || !t1) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_table_insert_clips: NULL column");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_TRY(stage_reserve(t, n));
+  void* d_ho;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(n_clips + 1) * 8, &d_ho));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_ho, hash_off, (uint64_t)(n_clips + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t *dk = key32, *dt = t1;
+  if (!(flags & SHZ_IN_DEVICE)) {
+    void *a, *b;
+    const uint64_t hi = hash_off[n_clips];
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, hi * 4, &a));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, hi * 4, &b));
+    SHZ_HIP(ctx, hipMemcpyAsync(a, key32, hi * 4, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(b, t1, hi * 4, hipMemcpyHostToDevice, ctx->stream));
+    dk = (const uint32_t*)a;
+    dt = (const uint32_t*)b;
+  }
+  hipLaunchKernelGGL(tbl_expand_clips_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dk, dt,
+                     (const uint64_t*)d_ho, n_clips, sid0, n, t->skey + t->ns, t->ssid + t->ns, t->soff + t->ns);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->ns += n;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_finalize(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t total = t->n + t->ns;
+  if (t->ns == 0 && (t->bucket || t->n == 0)) {
+    if (!t->bucket) {  // empty table: one empty bucket
+      SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
+      SHZ_HIP(ctx, hipMemsetAsync(t->bucket, 0, 8, ctx->stream));
+      t->nbuckets = 1;
+    }
+    return SHZ_OK;
+  }
+  if (total >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "table limited to < 2^32 rows (have %llu)", (unsigned long long)total);
+  void *k0, *k1, *v0, *v1, *mx, *fl, *ps, *tot;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, total * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, total * 8, &k1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, total * 8, &v0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, total * 8, &v1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &mx));
+  SHZ_HIP(ctx, hipMemsetAsync(mx, 0, 64, ctx->stream));
+  if (t->n)
+    hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream, t->key, t->sid,
+                       t->off, t->n, (uint64_t)0, (uint64_t*)k0, (uint32_t*)v0, (uint32_t*)mx);
+  if (t->ns)
+    hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream, t->skey,
+                       t->ssid, t->soff, t->ns, t->n, (uint64_t*)k0, (uint32_t*)v0, (uint32_t*)mx);
+  SHZ_HIP(ctx, hipGetLastError());
+  uint32_t maxes[2];
+  SHZ_HIP(ctx, hipMemcpyAsync(maxes, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->max_sid = maxes[0];
+  t->max_off = maxes[1];
+  // 1) stable sort by (sid, off) carrying the key, 2) stable sort by key carrying (sid, off)
+  int sel = 0;
+  uint64_t *ka = (uint64_t*)k0, *kb = (uint64_t*)k1;
+  void *va = v0, *vb = v1;
+  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 0, bits_for(maxes[1]), &sel));
+  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 32, 32 + bits_for(maxes[0]), &sel));
+  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+  hipLaunchKernelGGL(tbl_swap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)ka,
+                     (const uint32_t*)va, total, kb, (uint64_t*)vb);
+  SHZ_HIP(ctx, hipGetLastError());
+  std::swap(ka, kb);
+  std::swap(va, vb);
+  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 8, total, 0, 32, &sel));
+  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+  // unique + compaction into fresh column arrays
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, total * 4, &fl));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, total * 4, &ps));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
+  hipLaunchKernelGGL(tbl_uniq_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint64_t*)ka, (const uint64_t*)va, total, (uint32_t*)fl);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, total, (uint64_t*)tot));
+  uint64_t nu = 0;
+  SHZ_HIP(ctx, hipMemcpyAsync(&nu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t *nk, *nsid, *noff;
+  if (hipMalloc(&nk, nu * 4 + 4) != hipSuccess || hipMalloc(&nsid, nu * 4 + 4) != hipSuccess ||
+      hipMalloc(&noff, nu * 4 + 4) != hipSuccess)
+    SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)nu);
+  hipLaunchKernelGGL(tbl_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint64_t*)ka, (const uint64_t*)va, (const uint32_t*)fl, (const uint32_t*)ps, total, nk, nsid,
+                     noff);
+  SHZ_HIP(ctx, hipGetLastError());
+  uint32_t last_key = 0;
+  SHZ_HIP(ctx, hipMemcpyAsync(&last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  void* olds[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
+  for (void* p : olds)
+    if (p) SHZ_HIP(ctx, hipFree(p));
+  t->key = nk; t->sid = nsid; t->off = noff;
+  t->skey = t->ssid = t->soff = nullptr;
+  t->ns = t->scap = 0;
+  t->n = nu;
+  t->nbuckets = (uint64_t)(last_key >> 8) + 1;
+  t->bucket = nullptr;
+  SHZ_HIP(ctx, hipMalloc(&t->bucket, (t->nbuckets + 1) * 4));
+  hipLaunchKernelGGL(tbl_bucket_kernel, dim3((unsigned)((t->nbuckets + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)t->key, (uint32_t)t->n, t->nbuckets, t->bucket);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged) {
+  if (!t) return SHZ_E_INVALID;
+  if (n_rows) *n_rows = t->n;
+  if (n_staged) *n_staged = t->ns;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap,
+                                    uint64_t* count) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (count) *count = t->n;
+  if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has %llu staged rows; call shz_table_finalize first", (unsigned long long)t->ns);
+  if (t->n > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)t->n);
+  if (t->n == 0) return SHZ_OK;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_HIP(ctx, hipMemcpyAsync(key32, t->key, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sid, t->sid, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(off, t->off, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_song_rows(shz_table* t, uint32_t sid, uint64_t* n_rows) {
+  if (!t || !n_rows) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has staged rows; call shz_table_finalize first");
+  *n_rows = 0;
+  if (t->n == 0) return SHZ_OK;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void* d;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &d));
+  SHZ_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(tbl_count_sid_kernel, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)t->sid, t->n, sid, (unsigned long long*)d);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipMemcpyAsync(n_rows, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+__global__ void tbl_lookup_count_kernel(const uint32_t* __restrict__ keys, uint64_t nk, const uint32_t* __restrict__ tkey,
+                                        uint32_t tn, const uint32_t* __restrict__ bucket, uint64_t nbuckets,
+                                        uint32_t* __restrict__ lo_out, uint64_t* __restrict__ cnt) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nk) return;
+  if (i == nk) { cnt[i] = 0; return; }
+  const uint32_t key = keys[i];
+  const uint64_t b = key >> 8;
+  uint32_t lo = 0, rows = 0;
+  if (b < nbuckets && tn) {
+    uint32_t l = bucket[b], h = bucket[b + 1];
+    const uint32_t h0 = h;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if (tkey[mid] < key) l = mid + 1; else h = mid; }
+    lo = l;
+    h = h0;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if (tkey[mid] <= key) l = mid + 1; else h = mid; }
+    rows = l - lo;
+  }
+  lo_out[i] = lo;
+  cnt[i] = rows;
+}
+
+__global__ void tbl_lookup_gather_kernel(const uint32_t* __restrict__ lo, const uint64_t* __restrict__ po, uint64_t nk,
+                                         uint64_t total, const uint32_t* __restrict__ tkey,
+                                         const uint32_t* __restrict__ tsid, const uint32_t* __restrict__ toff,
+                                         uint32_t* __restrict__ okey, uint32_t* __restrict__ osid,
+                                         uint32_t* __restrict__ ooff) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  uint64_t l = 0, h = nk;
+  while (h - l > 1) { uint64_t mid = (l + h) >> 1; if (po[mid] <= p) l = mid; else h = mid; }
+  const uint32_t row = lo[l] + (uint32_t)(p - po[l]);
+  okey[p] = tkey[row];
+  osid[p] = tsid[row];
+  ooff[p] = toff[row];
+}
+
+extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t n_keys, uint32_t* key32, uint32_t* sid,
+                                    uint32_t* off, uint64_t cap, uint64_t* count) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (count) *count = 0;
+  if (t->ns || !t->bucket) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (n_keys == 0) return SHZ_OK;
+  if (!keys) SHZ_FAIL(ctx, SHZ_E_INVALID, "keys is NULL");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void *dk, *dlo, *dcnt, *dpo, *tot;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, n_keys * 4, &dk));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n_keys * 4, &dlo));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (n_keys + 1) * 8, &dcnt));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (n_keys + 1) * 8, &dpo));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &tot));
+  SHZ_HIP(ctx, hipMemcpyAsync(dk, keys, n_keys * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(tbl_lookup_count_kernel, dim3((unsigned)((n_keys + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)dk, n_keys, (const uint32_t*)t->key, (uint32_t)t->n, (const uint32_t*)t->bucket,
+                     t->nbuckets, (uint32_t*)dlo, (uint64_t*)dcnt);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)dcnt, (uint64_t*)dpo, n_keys + 1, (uint64_t*)tot));
+  uint64_t total = 0;
+  SHZ_HIP(ctx, hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (count) *count = total;
+  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)total);
+  if (total == 0) return SHZ_OK;
+  if (!key32 || !sid || !off) SHZ_FAIL(ctx, SHZ_E_INVALID, "NULL output column");
+  void *ok, *os, *oo;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, total * 4, &ok));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, total * 4, &os));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, total * 4, &oo));
+  hipLaunchKernelGGL(tbl_lookup_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)dlo, (const uint64_t*)dpo, n_keys, total, (const uint32_t*)t->key,
+                     (const uint32_t*)t->sid, (const uint32_t*)t->off, (uint32_t*)ok, (uint32_t*)os, (uint32_t*)oo);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipMemcpyAsync(key32, ok, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(sid, os, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(off, oo, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------- all-gather build
+extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
+  if (!t || !c) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  int rank, nranks;
+  shz_comm_info(c, &rank, &nranks);
+  // 1) exchange staged-row counts
+  void* d_cnt;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
+  uint64_t mine = t->ns;
+  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
+  std::vector<uint64_t> cnt(nranks);
+  SHZ_HIP(ctx, hipMemcpyAsync(cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t total = 0;
+  std::vector<uint64_t> displ(nranks), bytes(nranks);
+  for (int r = 0; r < nranks; ++r) {
+    displ[r] = total * 4;
+    bytes[r] = cnt[r] * 4;
+    total += cnt[r];
+  }
+  if (bytes_recv) *bytes_recv = (total - mine) * 12;
+  if (total == 0) return shz_table_finalize(t);
+  // 2) per column: every rank's block lands at its displacement in the gathered column
+  uint32_t* g[3];
+  for (int i = 0; i < 3; ++i)
+    if (hipMalloc(&g[i], total * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
+  const uint32_t* mine_cols[3] = {t->skey, t->ssid, t->soff};
+  for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, mine_cols[i], g[i], bytes.data(), displ.data()));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // 3) the gathered columns become the staged rows; finalize sorts + dedups them with the existing table
+  void* olds[] = {t->skey, t->ssid, t->soff};
+  for (void* p : olds)
+    if (p) SHZ_HIP(ctx, hipFree(p));
+  t->skey = g[0]; t->ssid = g[1]; t->soff = g[2];
+  t->ns = t->scap = total;
+  return shz_table_finalize(t);
+}
+
+// ======================================================================================== match
+#define QOFF_BITS 20
+#define QKEY_SHIFT 20
+#define QIDX_SHIFT 52
+#define MAX_Q_SUB 4096
+
+__global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint32_t* __restrict__ q_off,
+                                 const uint64_t* __restrict__ query_off /*sub-batch CSR, nq+1*/, uint32_t nq, uint64_t m,
+                                 uint64_t* __restrict__ c, uint32_t* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint64_t h = query_off[0] + i;
+  uint32_t lo = 0, hi = nq;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (query_off[mid] <= h) lo = mid; else hi = mid;
+  }
+  const uint32_t o = q_off[h];
+  if (o >> QOFF_BITS) atomicOr(err, 1u);
+  c[i] = ((uint64_t)lo << QIDX_SHIFT) | ((uint64_t)key32[h] << QKEY_SHIFT) | (o & ((1u << QOFF_BITS) - 1));
+}
+
+// flag[i] = 1 where (c[i] >> shift) differs from its predecessor
+__global__ void m_head_flag_kernel(const uint64_t* __restrict__ c, uint64_t n, int shift, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || (c[i] >> shift) != (c[i - 1] >> shift)) ? 1u : 0u;
+}
+
+__global__ void m_compact_vals_kernel(const uint64_t* __restrict__ c, const uint32_t* __restrict__ flag,
+                                      const uint32_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) out[pos[i]] = c[i];
+}
+
+// starts[pos[i]] = i for heads; starts[n_heads] = n
+__global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n,
+                                     const uint64_t* __restrict__ n_heads, uint32_t* __restrict__ starts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) starts[*n_heads] = (uint32_t)n;
+  if (i < n && flag[i]) starts[pos[i]] = (uint32_t)i;
+}
+
+__global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
+                               const uint32_t* __restrict__ tkey, uint32_t tn, const uint32_t* __restrict__ bucket,
+                               uint64_t nbuckets, uint32_t* __restrict__ g_lo, uint32_t* __restrict__ g_rows,
+                               uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t rows = 0;
+  if (g < ng) {
+    const uint32_t e0 = gs[g];
+    const uint32_t key = (uint32_t)(E[e0] >> QKEY_SHIFT);
+    const uint64_t b = key >> 8;
+    uint32_t lo = 0;
+    if (b < nbuckets && tn) {
+      uint32_t l = bucket[b], h = bucket[b + 1];
+      const uint32_t h0 = h;
+      while (l < h) {  // lower_bound(key)
+        uint32_t mid = l + ((h - l) >> 1);
+        if (tkey[mid] < key) l = mid + 1; else h = mid;
+      }
+      lo = l;
+      h = h0;
+      while (l < h) {  // upper_bound(key)
+        uint32_t mid = l + ((h - l) >> 1);
+        if (tkey[mid] <= key) l = mid + 1; else h = mid;
+      }
+      rows = l - lo;
+    }
+    g_lo[g] = lo;
+    g_rows[g] = rows;
+    g_pairs[g] = (uint64_t)rows * (gs[g + 1] - e0);
+  } else if (g == ng) {
+    g_pairs[g] = 0;  // sentinel so the exclusive scan yields po[ng] = total
+  }
+  unsigned long long s = rows;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor((long long)s, d, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total, s);
+}
+
+__global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu, const uint32_t* __restrict__ gs,
+                                     uint32_t ng, const uint64_t* __restrict__ po, uint32_t nq,
+                                     uint32_t* __restrict__ nhash, uint64_t* __restrict__ npairs) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  // elements of q: E in [q << 52, (q+1) << 52)
+  auto lb_e = [&](uint64_t target) {
+    uint32_t l = 0, h = mu;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if (E[mid] < target) l = mid + 1; else h = mid; }
+    return l;
+  };
+  auto lb_g = [&](uint64_t target) {
+    uint32_t l = 0, h = ng;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if (E[gs[mid]] < target) l = mid + 1; else h = mid; }
+    return l;
+  };
+  const uint64_t a = (uint64_t)q << QIDX_SHIFT, b = (uint64_t)(q + 1) << QIDX_SHIFT;
+  nhash[q] = lb_e(b) - lb_e(a);
+  npairs[q] = po[lb_g(b)] - po[lb_g(a)];
+}
+
+struct m_bits { int sb, dbits, qb; };
+
+__global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
+                                const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
+                                const uint32_t* __restrict__ tsid, const uint32_t* __restrict__ toff, uint64_t P,
+                                m_bits mb, uint64_t* __restrict__ v) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  uint32_t l = 0, h = ng;  // last g with po[g] <= p
+  while (h - l > 1) {
+    uint32_t mid = (l + h) >> 1;
+    if (po[mid] <= p) l = mid; else h = mid;
+  }
+  const uint32_t g = l;
+  const uint32_t e0 = gs[g], noff = gs[g + 1] - e0;
+  const uint64_t r = p - po[g];
+  const uint32_t row = g_lo[g] + (uint32_t)(r / noff), oi = (uint32_t)(r % noff);
+  const uint64_t e = E[e0 + oi];
+  const uint64_t q = e >> QIDX_SHIFT;
+  const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
+  const uint64_t dprime = (uint64_t)toff[row] + (1u << QOFF_BITS) - qo;  // delta + 2^20 > 0
+  v[p] = ((((q << mb.sb) | tsid[row]) << mb.dbits | dprime) << 1) | (oi == 0 ? 1u : 0u);
+}
+
+// one thread per run that opens a (query, sid) group: fold its runs (ascending delta) into
+// (best count, first delta reaching it, dedup rows)
+__global__ void m_group_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs, uint32_t nr, m_bits mb,
+                               uint32_t* __restrict__ g_head, uint32_t* __restrict__ g_cnt,
+                               uint32_t* __restrict__ g_delta, uint32_t* __restrict__ g_dedup) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nr) return;
+  const int gshift = mb.dbits + 1;
+  const uint64_t grp = v[rs[r]] >> gshift;
+  const bool head = r == 0 || (v[rs[r - 1]] >> gshift) != grp;
+  g_head[r] = head ? 1u : 0u;
+  if (!head) return;
+  const uint64_t dmask = (1ull << mb.dbits) - 1;
+  uint32_t best = 0, bestd = 0, cur = 0, dedup = 0;
+  uint64_t curd = ~0ull;
+  for (uint32_t k = r; k < nr; ++k) {
+    const uint64_t val = v[rs[k]];
+    if ((val >> gshift) != grp) break;
+    const uint32_t len = rs[k + 1] - rs[k];
+    const uint64_t d = (val >> 1) & dmask;
+    if (d != curd) {
+      if (cur > best) { best = cur; bestd = (uint32_t)curd; }
+      curd = d;
+      cur = 0;
+    }
+    cur += len;
+    if (val & 1) dedup += len;
+  }
+  if (cur > best) { best = cur; bestd = (uint32_t)curd; }
+  g_cnt[r] = best;
+  g_delta[r] = bestd;
+  g_dedup[r] = dedup;
+}
+
+// one wave per query: top-n groups by (count desc, sid asc)
+__global__ __launch_bounds__(64) void m_topn_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
+                                                    uint32_t nr, m_bits mb, const uint32_t* __restrict__ g_head,
+                                                    const uint32_t* __restrict__ g_cnt,
+                                                    const uint32_t* __restrict__ g_delta,
+                                                    const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
+                                                    uint32_t* __restrict__ out_sid, int32_t* __restrict__ out_delta,
+                                                    uint32_t* __restrict__ out_aligned, uint32_t* __restrict__ out_dedup,
+                                                    uint32_t* __restrict__ out_nres) {
+  const uint32_t q = blockIdx.x;
+  if (q >= nq) return;
+  const int lane = threadIdx.x;
+  const int qshift = mb.sb + mb.dbits + 1;
+  auto lb = [&](uint64_t target) {  // first run whose query index >= target
+    uint32_t l = 0, h = nr;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if ((v[rs[mid]] >> qshift) < target) l = mid + 1; else h = mid; }
+    return l;
+  };
+  const uint32_t r0 = lb(q), r1 = lb((uint64_t)q + 1);
+  const uint64_t smask = (1ull << mb.sb) - 1;
+  uint64_t prev = ~0ull;  // packed rank of the previous winner; candidates must rank strictly below it
+  uint32_t found = 0;
+  for (uint32_t n = 0; n < topn; ++n) {
+    uint64_t best = 0;
+    uint32_t bestr = 0xFFFFFFFFu;
+    for (uint32_t r = r0 + lane; r < r1; r += 64) {
+      if (!g_head[r]) continue;
+      const uint32_t sid = (uint32_t)((v[rs[r]] >> (mb.dbits + 1)) & smask);
+      const uint64_t packed = ((uint64_t)g_cnt[r] << 32) | (0xFFFFFFFFu - sid);
+      if (packed < prev && (bestr == 0xFFFFFFFFu || packed > best)) { best = packed; bestr = r; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint64_t ob = (uint64_t)__shfl_xor((long long)best, d, 64);
+      const uint32_t orr = (uint32_t)__shfl_xor((int)bestr, d, 64);
+      if (orr != 0xFFFFFFFFu && (bestr == 0xFFFFFFFFu || ob > best)) { best = ob; bestr = orr; }
+    }
+    if (bestr == 0xFFFFFFFFu) break;  // uniform after the butterfly
+    if (lane == 0) {
+      const uint64_t o = (uint64_t)q * topn + n;
+      out_sid[o] = 0xFFFFFFFFu - (uint32_t)best;
+      out_aligned[o] = (uint32_t)(best >> 32);
+      out_delta[o] = (int32_t)((int64_t)g_delta[bestr] - (int64_t)(1u << QOFF_BITS));
+      out_dedup[o] = g_dedup[bestr];
+    }
+    prev = best;
+    ++found;
+  }
+  if (lane == 0) out_nres[q] = found;
+}
+
+static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                                   const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
+                                   uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
+                                   uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs) {
+  if (!ctx || !t) return SHZ_E_INVALID;
+  if (t->ctx != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "table belongs to another ctx");
+  if (t->ns || !t->bucket) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (n_queries == 0) return SHZ_OK;
+  if (!query_off || !out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres)
+    SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_batch: NULL buffer");
+  if (topn < 1 || topn > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->st_rows = ctx->st_pairs = ctx->st_keys = 0;
+  const uint64_t P_BUDGET = 1ull << 28;
+  m_bits mb;
+  mb.sb = bits_for(t->max_sid);
+  mb.dbits = bits_for((uint64_t)t->max_off + (1ull << QOFF_BITS));
+  // whole query set on the device once
+  const uint64_t h0 = query_off[0], h1 = query_off[n_queries];
+  const uint32_t *d_key = key32, *d_qo = q_off;
+  if (!(flags & SHZ_IN_DEVICE) && h1 > 0) {
+    void *a, *b;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, h1 * 4, &a));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, h1 * 4, &b));
+    SHZ_HIP(ctx, hipMemcpyAsync(a, key32, h1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(b, q_off, h1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_key = (const uint32_t*)a;
+    d_qo = (const uint32_t*)b;
+  }
+  (void)h0;
+  uint32_t q0 = 0;
+  uint32_t step = std::min<uint32_t>(n_queries, MAX_Q_SUB);
+  while (q0 < n_queries) {
+    uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
+    // shrink so the element count stays sortable
+    while (nq > 1 && query_off[q0 + nq] - query_off[q0] >= (1ull << 31)) nq /= 2;
+    const uint64_t m = query_off[q0 + nq] - query_off[q0];
+    if (m >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u has too many hashes", q0);
+    mb.qb = bits_for(nq - 1);
+    if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
+      if (nq > 1) { step = nq / 2; continue; }
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
+    }
+    void *d_qoff, *c0, *c1, *fl, *ps, *tot, *err;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
+    SHZ_HIP(ctx, hipMemcpyAsync(d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &tot));
+    err = (char*)tot + 128;
+    SHZ_HIP(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
+    uint32_t* h_nres = out_nres + q0;
+    if (m == 0) {
+      for (uint32_t q = 0; q < nq; ++q) {
+        h_nres[q] = 0;
+        if (out_nhash) out_nhash[q0 + q] = 0;
+        if (out_npairs) out_npairs[q0 + q] = 0;
+      }
+      q0 += nq;
+      continue;
+    }
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, m * 8, &c0));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, m * 8, &c1));
+    hipLaunchKernelGGL(m_compose_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, d_key, d_qo, (const uint64_t*)d_qoff, nq,
+                       m, (uint64_t*)c0, (uint32_t*)err);
+    SHZ_HIP(ctx, hipGetLastError());
+    int sel = 0;
+    SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)c0, (uint64_t*)c1, nullptr, nullptr, 0, m, 0, QIDX_SHIFT + mb.qb, &sel));
+    uint64_t* cs = sel ? (uint64_t*)c1 : (uint64_t*)c0;   // sorted
+    uint64_t* E = sel ? (uint64_t*)c0 : (uint64_t*)c1;    // unique elements go to the other buffer
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, m * 4, &fl));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, m * 4, &ps));
+    // unique (query, key, off)
+    hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs, m, 0, (uint32_t*)fl);
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, (uint64_t*)tot));
+    hipLaunchKernelGGL(m_compact_vals_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs,
+                       (const uint32_t*)fl, (const uint32_t*)ps, m, E);
+    SHZ_HIP(ctx, hipGetLastError());
+    uint64_t mu = 0;
+    uint32_t herr = 0;
+    SHZ_HIP(ctx, hipMemcpyAsync(&mu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (herr) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
+    // groups = distinct (query, key)
+    void *gs, *glo, *grows, *gpairs, *po;
+    hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint64_t*)E, mu, QKEY_SHIFT,
+                       (uint32_t*)fl);
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, mu, (uint64_t*)tot + 1));
+    uint64_t ng64 = 0;
+    SHZ_HIP(ctx, hipMemcpyAsync(&ng64, (uint64_t*)tot + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t ng = (uint32_t)ng64;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)(ng + 1) * 4, &gs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)(ng + 1) * 4, &glo));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)(ng + 1) * 4, &grows));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)(ng + 1) * 8, &gpairs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, (uint64_t)(ng + 1) * 8, &po));
+    hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
+                       (const uint32_t*)ps, mu, (const uint64_t*)tot + 1, (uint32_t*)gs);
+    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk((uint64_t)ng + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                       (const uint32_t*)gs, ng, (const uint32_t*)t->key, (uint32_t)t->n, (const uint32_t*)t->bucket,
+                       t->nbuckets, (uint32_t*)glo, (uint32_t*)grows, (uint64_t*)gpairs, (unsigned long long*)tot + 2);
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, (uint64_t)ng + 1, (uint64_t*)tot + 3));
+    uint64_t P = 0, rows_total = 0;
+    SHZ_HIP(ctx, hipMemcpyAsync(&P, (uint64_t*)tot + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(&rows_total, (uint64_t*)tot + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (P > P_BUDGET && nq > 1) {  // too many pairs for one pass: retry with fewer queries
+      step = std::max<uint32_t>(1, nq / 2);
+      continue;
+    }
+    if (P >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u alone produces %llu matches (limit 2^32)", q0, (unsigned long long)P);
+    ctx->st_rows += rows_total;
+    ctx->st_pairs += P;
+    ctx->st_keys += ng;
+    // per-query counters
+    void *d_nh, *d_np;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)nq * 4, &d_nh));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)nq * 8, &d_np));
+    hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
+                       (const uint32_t*)gs, ng, (const uint64_t*)po, nq, (uint32_t*)d_nh, (uint64_t*)d_np);
+    SHZ_HIP(ctx, hipGetLastError());
+    if (out_nhash) SHZ_HIP(ctx, hipMemcpyAsync(out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_npairs) SHZ_HIP(ctx, hipMemcpyAsync(out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // device result buffers
+    void *r_sid, *r_delta, *r_al, *r_dd, *r_n;
+    const uint64_t nres = (uint64_t)nq * topn;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, nres * 4, &r_dd));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)nq * 4, &r_n));
+    SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
+    if (P > 0) {
+      // expand -> sort -> runs -> groups -> top-n.  E lives in one of SORT_A/B; the pair buffers use SORT_C/D.
+      void *v0, *v1, *rs, *gh, *gc, *gd, *gdd;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
+      hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                         ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)t->sid, (const uint32_t*)t->off, P,
+                         mb, (uint64_t*)v0);
+      SHZ_HIP(ctx, hipGetLastError());
+      SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)v0, (uint64_t*)v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
+      const uint64_t* vs = sel ? (const uint64_t*)v1 : (const uint64_t*)v0;
+      void* other = sel ? v0 : v1;  // free pair buffer: reuse for flags/positions (P*8 bytes = 2 x P u32)
+      uint32_t* rfl = (uint32_t*)other;
+      uint32_t* rps = rfl + P;
+      hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, vs, P, 0, rfl);
+      SHZ_TRY(shz_scan_u32(ctx, rfl, rps, P, (uint64_t*)tot + 4));
+      uint64_t nr64 = 0;
+      SHZ_HIP(ctx, hipMemcpyAsync(&nr64, (uint64_t*)tot + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const uint32_t nr = (uint32_t)nr64;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 4, &gh));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nr * 4, &gc));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
+      hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl,
+                         (const uint32_t*)rps, P, (const uint64_t*)tot + 4, (uint32_t*)rs);
+      hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                         (uint32_t*)gh, (uint32_t*)gc, (uint32_t*)gd, (uint32_t*)gdd);
+      hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(64), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                         (const uint32_t*)gh, (const uint32_t*)gc, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
+                         (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+    const uint64_t o0 = (uint64_t)q0 * topn;
+    SHZ_HIP(ctx, hipMemcpyAsync(out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    q0 += nq;
+  }
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, uint64_t* distinct_keys) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (rows_scanned) *rows_scanned = ctx->st_rows;
+  if (pairs) *pairs = ctx->st_pairs;
+  if (distinct_keys) *distinct_keys = ctx->st_keys;
+  return SHZ_OK;
+}

@@ -1,0 +1,163 @@
+"""HipFingerprintDB -- the HBM-resident table behind the reference's duck-typed database
+interface (MySQLDatabase, mysql_database.py:28-255), registrable as ``DATABASES['hip']``.
+
+What lives where: the ``fingerprints`` rows (hash, song_id, offset) are device columns inside
+``libshz.so`` (sorted by key, UNIQUE(song_id, offset, hash) enforced at finalize like the
+MySQL constraint + INSERT IGNORE); the tiny ``songs`` table is a host dict.  ``cursor()``
+emulates just enough of the SQL surface for the reference's own ``return_matches``
+(recognizer.py:251-259) to run unchanged against it; ``match()`` is the fast batched path.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from datetime import datetime
+
+import numpy as np
+
+from . import _ffi
+from . import get_context, hex_of_keys, key_of_hex
+
+
+class _Cursor:
+    def __init__(self, db):
+        self.db, self.rows, self.lastrowid = db, [], None
+
+    def execute(self, query, values=()):
+        q = " ".join(str(query).split()).upper()
+        self.rows = []
+        if q.startswith("SELECT HEX(`HASH`)") and " IN (" in q:          # SELECT_MULTIPLE
+            self.rows = self.db._select_multiple(list(values))
+        elif q.startswith("CREATE TABLE") or q.startswith("DROP TABLE"):
+            pass
+        elif q.startswith("DELETE FROM `SONGS` WHERE `FINGERPRINTED` = 0"):  # DELETE_UNFINGERPRINTED
+            self.db.delete_unfingerprinted()
+        else:
+            raise NotImplementedError(f"HipFingerprintDB cursor does not implement: {query!r}")
+
+    def executemany(self, query, seq):
+        q = " ".join(str(query).split()).upper()
+        if q.startswith("INSERT IGNORE INTO `FINGERPRINTS`"):                # INSERT_FINGERPRINT
+            rows = list(seq)
+            if rows:
+                self.db._insert_rows([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows])
+        else:
+            raise NotImplementedError(f"HipFingerprintDB cursor does not implement: {query!r}")
+
+    def __iter__(self):
+        return iter(self.rows)
+
+    def fetchone(self):
+        return self.rows[0] if self.rows else None
+
+
+class HipFingerprintDB:
+    type = "hip"
+
+    # SQL text the reference passes to cursor.execute (mysql_database.py:32-141); kept so callers
+    # that reference db.CREATE_* / db.SELECT_MULTIPLE keep working -- the cursor recognises them.
+    CREATE_SONGS_TABLE = "CREATE TABLE IF NOT EXISTS `songs` (...)"
+    CREATE_FINGERPRINTS_TABLE = "CREATE TABLE IF NOT EXISTS `fingerprints` (...)"
+    DELETE_UNFINGERPRINTED = "DELETE FROM `songs` WHERE `fingerprinted` = 0;"
+    INSERT_FINGERPRINT = "INSERT IGNORE INTO `fingerprints` (`song_id`, `hash`, `offset`) VALUES (%s, UNHEX(%s), %s);"
+    SELECT_MULTIPLE = "SELECT HEX(`hash`), `song_id`, `offset` FROM `fingerprints` WHERE `hash` IN (%s);"
+    IN_MATCH = "UNHEX(%s)"
+
+    def __init__(self, device: int | None = None, ctx: _ffi.Context = None, **options):
+        self.ctx = ctx or get_context(device)
+        self.table = _ffi.Table(self.ctx)
+        self.songs = {}          # sid -> dict(song_name, file_sha1, total_hashes, fingerprinted, date_created)
+        self._next_sid = 1       # AUTO_INCREMENT (mysql_database.py:34)
+        self._dirty = False
+        self._options = options
+
+    # ---- lifecycle ---------------------------------------------------------------------------
+    def setup(self) -> None:
+        self.delete_unfingerprinted()
+
+    def after_fork(self) -> None:
+        raise RuntimeError("a GPU context cannot be shared across fork(); create the DB in the child")
+
+    def close(self):
+        self.table.close()
+
+    @contextmanager
+    def cursor(self, **options):
+        yield _Cursor(self)
+
+    # ---- songs table (host) ---------------------------------------------------------------------
+    def insert_song(self, song_name: str, file_hash: str, total_hashes: int) -> int:
+        sid = self._next_sid
+        self._next_sid += 1
+        self.songs[sid] = {"song_name": song_name, "file_sha1": str(file_hash).upper(), "total_hashes": int(total_hashes),
+                           "fingerprinted": 0, "date_created": datetime.now()}
+        return sid
+
+    def set_song_fingerprinted(self, song_id):
+        self.songs[song_id]["fingerprinted"] = 1
+
+    def delete_unfingerprinted(self):
+        """DELETE_UNFINGERPRINTED (mysql_database.py:132-134).  Rows of such songs stay in the device
+        table but can never be returned by get_songs; a rebuild drops them."""
+        for sid in [s for s, v in self.songs.items() if not v["fingerprinted"]]:
+            del self.songs[sid]
+
+    def get_songs(self):
+        """SELECT_SONGS rows: (song_id, song_name, HEX(file_sha1), total_hashes, date_created)."""
+        return [(sid, s["song_name"], s["file_sha1"], s["total_hashes"], s["date_created"])
+                for sid, s in sorted(self.songs.items()) if s["fingerprinted"]]
+
+    def get_song_by_id(self, song_id: int):
+        s = self.songs[int(song_id)]
+        return {"song_name": s["song_name"], "total_hashes": s["total_hashes"], "file_sha1": s["file_sha1"]}
+
+    def get_metadata(self, song_id: int):
+        raise NotImplementedError("the FMA METADATA table is external to the fingerprint path")
+
+    # ---- fingerprints table (device) -------------------------------------------------------------
+    def _insert_rows(self, sids, hexes, offsets):
+        keys = np.fromiter((key_of_hex(h) for h in hexes), np.uint32, len(hexes))
+        self.table.insert(keys, np.asarray(sids, np.uint32), np.asarray([int(o) for o in offsets], np.uint32))
+        self._dirty = True
+
+    def insert_hashes(self, song_id: int, hashes, batch_size: int = 1000):
+        """mysql_database.py:167-181: (hex, offset) pairs of one song; duplicates ignored."""
+        hashes = list(hashes)
+        if hashes:
+            self._insert_rows(np.full(len(hashes), song_id, np.uint32), [h for h, _ in hashes], [o for _, o in hashes])
+
+    def insert_keys(self, song_id, key32, offsets):
+        """Packed-key form of insert_hashes (no hex round trip); song_id scalar or array."""
+        self.table.insert(key32, song_id, offsets)
+        self._dirty = True
+
+    def insert_clips(self, key32, t1, hash_off, sid0, device=False):
+        """Rows of many songs at once: clip c of the CSR gets song id sid0 + c."""
+        self.table.insert_clips(key32, t1, hash_off, sid0, device=device)
+        self._dirty = True
+
+    def finalize(self):
+        if self._dirty or self.table.rows()[1] or self.table.rows()[0] == 0:
+            self.table.finalize()
+            self._dirty = False
+
+    def _select_multiple(self, hex_values):
+        self.finalize()
+        keys = []
+        for h in hex_values:
+            try:
+                keys.append(key_of_hex(h))
+            except KeyError:
+                pass  # a hash this process never produced cannot be in the table either
+        if not keys:
+            return []
+        k, s, o = self.table.lookup(np.asarray(keys, np.uint32))
+        hexes = hex_of_keys(self.ctx, k)
+        return [(h.upper(), int(a), int(b)) for h, a, b in zip(hexes, s.tolist(), o.tolist())]  # HEX() upper-cases
+
+    def match(self, key32, q_off, query_off, topn=2):
+        self.finalize()
+        return self.table.match(key32, q_off, query_off, topn)
+
+    def num_fingerprints(self) -> int:
+        self.finalize()
+        return self.table.rows()[0]
