@@ -68,7 +68,6 @@ extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
             hipMemcpy(ctx->d_window, win.data(), sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(ctx->d_twiddle, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(ctx->d_sine_lut, lut.data(), sizeof(int16_t) * 4096, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipEventCreate(&ctx->pev[0]) == hipSuccess && hipEventCreate(&ctx->pev[1]) == hipSuccess;
   if (!ok) {
     shz_ctx_destroy(ctx);
     return SHZ_E_HIP;
@@ -91,8 +90,11 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
       (void)hipEventDestroy(e[0]);
       (void)hipEventDestroy(e[1]);
     }
-  if (ctx->pev[0]) (void)hipEventDestroy(ctx->pev[0]);
-  if (ctx->pev[1]) (void)hipEventDestroy(ctx->pev[1]);
+  for (auto* v : {&ctx->prof_pending, &ctx->prof_free})
+    for (auto& r : *v) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SHZ_OK;
@@ -179,8 +181,40 @@ extern "C" int32_t shz_timer_stop(shz_ctx* ctx, int32_t slot, float* ms) {
   return SHZ_OK;
 }
 
+void shz_prof_begin(shz_ctx* ctx, int which) {
+  shz_prof_rec r;
+  if (!ctx->prof_free.empty()) {
+    r = ctx->prof_free.back();
+    ctx->prof_free.pop_back();
+  } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+    return;
+  }
+  r.which = which;
+  (void)hipEventRecord(r.a, ctx->stream);
+  ctx->prof_pending.push_back(r);
+}
+
+void shz_prof_end(shz_ctx* ctx) {
+  if (!ctx->prof_pending.empty()) (void)hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
+}
+
+static void prof_drain(shz_ctx* ctx) {
+  if (ctx->prof_pending.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->prof_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      ctx->kernel_ms[r.which] += ms;
+      ctx->kernel_launches[r.which] += 1;
+    }
+    ctx->prof_free.push_back(r);
+  }
+  ctx->prof_pending.clear();
+}
+
 extern "C" int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled) {
   if (!ctx) return SHZ_E_INVALID;
+  prof_drain(ctx);
   ctx->profiling = enabled != 0;
   for (int i = 0; i < 8; ++i) {
     ctx->kernel_ms[i] = 0;
@@ -191,6 +225,7 @@ extern "C" int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled) {
 
 extern "C" int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t* launches) {
   if (!ctx || which < 0 || which >= 8) return SHZ_E_INVALID;
+  prof_drain(ctx);
   if (total_ms) *total_ms = ctx->kernel_ms[which];
   if (launches) *launches = ctx->kernel_launches[which];
   return SHZ_OK;

@@ -31,6 +31,7 @@
     if (_s != SHZ_OK) return _s;       \
   } while (0)
 
+struct shz_prof_rec;
 // a growable device buffer owned by the ctx (scratch arena slot)
 struct shz_buf {
   void* p = nullptr;
@@ -83,7 +84,8 @@ struct shz_ctx {
   bool profiling = false;
   float kernel_ms[8] = {0};
   uint32_t kernel_launches[8] = {0};
-  hipEvent_t pev[2] = {nullptr, nullptr};
+  std::vector<struct shz_prof_rec> prof_pending;  // recorded, not yet resolved
+  std::vector<struct shz_prof_rec> prof_free;
   // match stats
   uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
 };
@@ -91,23 +93,15 @@ struct shz_ctx {
 // ensure ws slot has >= bytes (grow-only; contents not preserved)
 int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out);
 
-// profiling helpers: bracket a kernel group with events when ctx->profiling
+// profiling helpers: bracket a kernel group with events when ctx->profiling.  Events are only
+// recorded here (no host sync inside a timed region); shz_get_kernel_ms drains them.
+struct shz_prof_rec { hipEvent_t a, b; int which; };
+void shz_prof_begin(shz_ctx* ctx, int which);
+void shz_prof_end(shz_ctx* ctx);
 struct shz_prof_scope {
   shz_ctx* c;
-  int which;
-  shz_prof_scope(shz_ctx* ctx, int w) : c(ctx), which(w) {
-    if (c->profiling) (void)hipEventRecord(c->pev[0], c->stream);
-  }
-  ~shz_prof_scope() {
-    if (c->profiling) {
-      (void)hipEventRecord(c->pev[1], c->stream);
-      (void)hipEventSynchronize(c->pev[1]);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, c->pev[0], c->pev[1]);
-      c->kernel_ms[which] += ms;
-      c->kernel_launches[which] += 1;
-    }
-  }
+  shz_prof_scope(shz_ctx* ctx, int w) : c(ctx) { if (c->profiling) shz_prof_begin(c, w); }
+  ~shz_prof_scope() { if (c->profiling) shz_prof_end(c); }
 };
 
 // ---- device primitives (shz_prims.hip) ------------------------------------------------

@@ -113,7 +113,7 @@ def test_ragged_batch_equals_single_calls(golden_dir, S, ctx, O):
         assert [h.encode() for h in S.hex_of_keys(ctx, k[ho[i]:ho[i + 1]])] == list(g[f"{p}hash_hex"]), name
     # odd sample offsets inside the packed PCM buffer (clips of odd length precede others) are covered above;
     # force tiny sub-batches: same answer
-    ctx.set_workspace_limit(64 * 2056 * 8 * 6)
+    ctx.set_workspace_limit(700 * 2056 * 8)  # one 30 s clip (644 frames) at a time
     try:
         k2, t2, ho2 = S.fingerprint_batch(clips, ctx=ctx)
     finally:
