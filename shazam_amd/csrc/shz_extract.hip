@@ -7,7 +7,7 @@
 //
 // Data layout in HBM (per sub-batch):
 //   pcm      int16, clips concatenated                                        (input)
-//   db       f64 [frame][DB_STRIDE=2056], frames of all clips concatenated   (stage buffer)
+//   pw       f64 [frame][DB_STRIDE=2056] POWER (0 stored as 1.0), all clips' frames  (stage buffer)
 //   mask     u64 [frame][n_slabs][4]  one bit per (frame, bin): peak          (stage buffer)
 //   peak_f/t u16/u32 in (clip, t asc, f asc) order                             (stage buffer)
 //   key32/t1 u32 in the reference's generation order                           (output)
@@ -18,9 +18,9 @@
 #define DB_STRIDE 2056  // 2049 bins padded so every row starts 64-byte aligned
 
 // ======================================================================================
-// K1: stft_psd_db.  One workgroup (256 threads) per frame, persistent over frames.
+// K1: stft_psd.  One workgroup (256 threads) per frame, persistent over frames.
 // real 4096-FFT = complex 2048-FFT (Stockham radix 8,8,8,4 through LDS) + split post-pass.
-// LDS: 2304 double2 data (index padded i + i/8 against bank conflicts) + 1025 double2 twiddles.
+// LDS: 2048 double2 data (XOR-swizzled index against bank conflicts) + 1025 double2 twiddles.
 // ======================================================================================
 typedef double2 cplx;
 
@@ -54,7 +54,8 @@ __device__ __forceinline__ void dft8(cplx* v) {
   v[0] = b0; v[1] = b4; v[2] = b1; v[3] = b5; v[4] = b2; v[5] = b6; v[6] = b3; v[7] = b7;
 }
 
-#define LPAD(i) ((i) + ((i) >> 3))
+// LDS index swizzle: conflict-free for the stride-8 writes of pass 1 without padding
+#define SWZ(i) ((i) ^ (((i) >> 3) & 7))
 
 struct stft_args {
   const int16_t* pcm;
@@ -63,19 +64,25 @@ struct stft_args {
   const uint32_t* clip_foff;   // [n_clips+1] first frame of each clip (sub-batch numbering)
   uint32_t n_clips;
   uint32_t total_frames;
-  double* out;                 // [total_frames][DB_STRIDE]
+  double* out;                 // [total_frames][DB_STRIDE] power, exact zeros stored as 1.0 (= 0 dB)
   const double* window;        // [4096]
   const cplx* tw;              // [1025] W4096^k
   double scale;                // 0.25 / (Fs * sum(w^2))
 };
 
-__global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
-  __shared__ cplx lds[2304 + 1025];
+// The staged spectrogram holds POWER, not dB: 10*log10 is strictly increasing, so the 21x21
+// max-equality test gives the same cells on P as on 10*log10(P); the log itself is evaluated
+// in peak_pick only for cells that pass it (the `> amp_min` test, __init__.py:161) and in
+// shz_stft_db for the whole array.  Exact-zero power maps to 1.0 because the reference maps it
+// to 0 dB (__init__.py:241), which keeps its rank against sub-unity cells.
+__global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
+  __shared__ cplx lds[2048 + 1025];
   cplx* buf = lds;
-  cplx* tw = lds + 2304;
+  cplx* tw = lds + 2048;
   const int j = threadIdx.x;
   for (int i = j; i < 1025; i += 256) tw[i] = a.tw[i];
   __syncthreads();
+  const int sw = (j >> 3) & 7;  // swizzle term of element j + 256 t
 
   for (uint32_t g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
     // clip of frame g (uniform binary search over the frame offsets)
@@ -105,16 +112,16 @@ __global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
       }
       v[t] = make_double2(x0 * w.x, x1 * w.y);
     }
-    // pass 1: Ns = 1 (no twiddles)
+    // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
     dft8(v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) buf[9 * j + r] = v[r];  // LPAD(8j + r)
+    for (int r = 0; r < 8; ++r) buf[(8 * j + r) ^ (j & 7)] = v[r];
     __syncthreads();
 
     // pass 2: Ns = 8, twiddles W_64^(k t) = W4096^(64 k t)
     {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
       __syncthreads();
       const int k = j & 7;
       const cplx w1 = tw[64 * k], w2 = tw[128 * k];
@@ -129,13 +136,13 @@ __global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
       dft8(v);
       const int base = ((j >> 3) << 6) + k;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) buf[LPAD(base + 8 * r)] = v[r];
+      for (int r = 0; r < 8; ++r) buf[(base + 8 * r) ^ r] = v[r];  // ((base + 8r) >> 3) & 7 == r
       __syncthreads();
     }
     // pass 3: Ns = 64, twiddles W_512^(k t) = W4096^(8 k t)
     {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
       __syncthreads();
       const int k = j & 63;
       const cplx w1 = tw[8 * k], w2 = tw[16 * k];
@@ -149,15 +156,16 @@ __global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
       v[7] = cmul(v[7], cmul(w3, w4));
       dft8(v);
       const int base = ((j >> 6) << 9) + k;
+      const int ks = (k >> 3) & 7;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) buf[LPAD(base + 64 * r)] = v[r];
+      for (int r = 0; r < 8; ++r) buf[(base + 64 * r) ^ ks] = v[r];
       __syncthreads();
     }
     // pass 4: Ns = 512, radix 4, two butterflies per thread (k = j and k = j + 256);
     // twiddles W_2048^(k t) = W4096^(2 k t)
     {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[LPAD(j + 256 * t)];
+      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
       __syncthreads();
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -166,42 +174,46 @@ __global__ __launch_bounds__(256, 3) void stft_psd_db_kernel(stft_args a) {
         const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
         cplx c0 = v[h], c1 = cmul(v[h + 2], w1), c2 = cmul(v[h + 4], w2), c3 = cmul(v[h + 6], w3);
         dft4(c0, c1, c2, c3);
-        buf[LPAD(k)] = c0;
-        buf[LPAD(k + 512)] = c1;
-        buf[LPAD(k + 1024)] = c2;
-        buf[LPAD(k + 1536)] = c3;
+        buf[k ^ sw] = c0;
+        buf[(k + 512) ^ sw] = c1;
+        buf[(k + 1024) ^ sw] = c2;
+        buf[(k + 1536) ^ sw] = c3;
       }
       __syncthreads();
     }
-    // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale, dB
+    // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale
     double* orow = a.out + (uint64_t)g * DB_STRIDE;
+    const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
       const int k = j + 256 * m;
       if (m == 4 && j != 0) break;
-      const cplx zk = buf[LPAD(k)];
-      const cplx zm = buf[LPAD((2048 - k) & 2047)];
+      const int km = (2048 - k) & 2047;
+      const cplx zk = buf[SWZ(k)];
+      const cplx zm = buf[SWZ(km)];
       const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
       const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
       const cplx wo = cmul(tw[k], o);
       const cplx xa = cadd(e, wo), xb = csub(e, wo);
-      double pa = fma(xa.x, xa.x, xa.y * xa.y) * a.scale;
-      double pb = fma(xb.x, xb.x, xb.y * xb.y) * a.scale;
-      if (k != 0) {  // bins 1..2047 doubled (mlab:339-345); bin 2048 pairs with k = 0
-        pa *= 2.0;
-        pb *= 2.0;
-      }
-      orow[k] = (pa != 0.0) ? 10.0 * log10(pa) : 0.0;
-      if (k != 1024) orow[2048 - k] = (pb != 0.0) ? 10.0 * log10(pb) : 0.0;
+      const double sc = (k != 0) ? scale2 : a.scale;  // bin 2048 pairs with k = 0: both unscaled
+      const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
+      const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
+      orow[k] = (pa != 0.0) ? pa : 1.0;
+      if (k != 1024) orow[2048 - k] = (pb != 0.0) ? pb : 1.0;
     }
     __syncthreads();  // buf is rewritten by the next frame's pass 1
   }
 }
 
 // ======================================================================================
-// K2: peak_pick.  Workgroup = (clip segment, slab of PK_SW bins); streams frames in time with a
-// 21-deep register history per thread; the 21-wide frequency max goes through an LDS row.
-// peak <=> A == max over 21x21 window clipped to the array, and A > amp_min (ties all count).
+// K2: peak_pick.  Workgroup = (clip segment, slab of PK_SW bins); streams frames in time.
+// peak <=> A == max over the 21x21 window clipped to the array, and A > amp_min (ties all count).
+// Frequency direction: the row goes through LDS, pair maxima p2[i] = max(x[i], x[i+1]) halve the
+// reads (10 x p2 + 1 x raw).  Time direction: van Herk / Gil-Werman with blocks of 21 frames held
+// in registers -- prefix max R of the current block, suffix maxima prevS of the previous one, so
+// the 21-frame window max costs 3 max ops per frame instead of 20.
+// POWER = true: values are power (see stft_psd_kernel) and the threshold is applied to
+// 10*log10(value); POWER = false: values are compared with amp_min directly (get_2D_peaks API).
 // ======================================================================================
 #define PK_SW 228
 #define PK_COLS 248
@@ -213,11 +225,13 @@ struct peak_seg {
   uint32_t t0, t1;   // output frames [t0, t1)
 };
 
-__global__ __launch_bounds__(256) void peak_pick_kernel(const double* __restrict__ A, uint32_t row_stride,
+template <bool POWER>
+__global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restrict__ A, uint32_t row_stride,
                                                         uint32_t n_bins, const peak_seg* __restrict__ segs,
                                                         uint32_t n_slabs, double amp_min,
                                                         uint64_t* __restrict__ mask) {
-  __shared__ double row[2][PK_COLS + 8];
+  __shared__ double raw[PK_PF][256];   // PK_PF consecutive frames' rows of this slab
+  __shared__ double pr2[PK_PF][256];   // pair maxima of the same rows
   const peak_seg sg = segs[blockIdx.y];
   const uint32_t slab = blockIdx.x;
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) void peak_pick_kernel(const double* __restrict
   int li;  // index in the LDS row = column - (slab*PK_SW - 10)
   if (j < PK_SW) li = j + 10;
   else if (j < PK_SW + 10) li = j - PK_SW;
-  else li = j - 10 + 10;  // j in [238,248) -> li in [238,248)
+  else li = j;  // j in [238,248) -> right halo; j >= 248 idle
   const long long col = (long long)slab * PK_SW - 10 + li;
   const bool loads = j < PK_COLS && col >= 0 && col < (long long)n_bins;
   const bool is_out = j < PK_SW && col < (long long)n_bins;
@@ -235,44 +249,81 @@ __global__ __launch_bounds__(256) void peak_pick_kernel(const double* __restrict
   const int end = (int)sg.t1 + 10;  // last iteration decides frame t1-1
   const double* src = A + (uint64_t)sg.gframe0 * row_stride + (loads ? col : 0);
 
-  double hraw[21], hm1[21], pre[PK_PF];
+  double prevS[21], cur[21], pre[PK_PF];
+  uint32_t fc = 0, fp = 0, sp = 0;  // row-max flags of the current / previous block, suffix-max flags
+  double R = NEG;
 #pragma unroll
-  for (int u = 0; u < 21; ++u) { hraw[u] = NEG; hm1[u] = NEG; }
+  for (int u = 0; u < 21; ++u) { prevS[u] = NEG; cur[u] = NEG; }
 #pragma unroll
   for (int p = 0; p < PK_PF; ++p) {
     const int t = lo + p;
     pre[p] = (loads && t < hi) ? src[(uint64_t)t * row_stride] : NEG;
   }
+  // blocks of 21 frames = 3 groups of PK_PF = 7 frames; one barrier triple per group.  Iterations
+  // past `end` in the last block run predicated (no loads, no output).
   for (int tb = lo; tb < end; tb += 21) {
 #pragma unroll
-    for (int u = 0; u < 21; ++u) {
-      const int t = tb + u;
-      if (t >= end) break;
-      const double v = pre[u % PK_PF];
-      {
-        const int tn = t + PK_PF;
-        pre[u % PK_PF] = (loads && tn < hi) ? src[(uint64_t)tn * row_stride] : NEG;
+    for (int g3 = 0; g3 < 21 / PK_PF; ++g3) {
+      double v[PK_PF], m1[PK_PF];
+#pragma unroll
+      for (int i = 0; i < PK_PF; ++i) {
+        v[i] = pre[i];
+        const int tn = tb + PK_PF * (g3 + 1) + i;  // next group's frame: keeps PK_PF rows in flight
+        pre[i] = (loads && tn < hi) ? src[(uint64_t)tn * row_stride] : NEG;
       }
-      double* r = row[t & 1];
-      if (j < PK_COLS) r[li] = v;
+      __syncthreads();  // every wave is done reading the previous group's rows
+      if (j < PK_COLS) {
+#pragma unroll
+        for (int i = 0; i < PK_PF; ++i) raw[i][li] = v[i];
+      }
       __syncthreads();
-      double m1 = NEG;
-      if (j < PK_SW) {
+      if (j < PK_COLS) {
 #pragma unroll
-        for (int d = 0; d < 21; ++d) m1 = fmax(m1, r[j + d]);  // columns li-10 .. li+10
+        for (int i = 0; i < PK_PF; ++i) pr2[i][li] = fmax(v[i], (li + 1 < PK_COLS) ? raw[i][li + 1] : NEG);
       }
-      hraw[u] = v;
-      hm1[u] = m1;
-      double m2 = hm1[0];
+      __syncthreads();
 #pragma unroll
-      for (int q = 1; q < 21; ++q) m2 = fmax(m2, hm1[q]);
-      const double cval = hraw[(u + 11) % 21];  // frame t - 10
-      const int tc = t - 10;
-      const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
-      const bool pk = is_out && in_seg && (cval == m2) && (cval > amp_min);
-      const unsigned long long bal = __ballot(pk);
-      if (in_seg && lane == 0)
-        mask[((uint64_t)(sg.gframe0 + tc) * n_slabs + slab) * 4 + wave] = bal;
+      for (int i = 0; i < PK_PF; ++i) {
+        double m = NEG;
+        if (j < PK_SW) {  // window columns j .. j+20 of the row = pairs (j, j+1) .. (j+18, j+19) and j+20
+          m = raw[i][j + 20];
+#pragma unroll
+          for (int d = 0; d < 10; ++d) m = fmax(m, pr2[i][j + 2 * d]);
+        }
+        m1[i] = m;
+      }
+      // time direction (registers only)
+#pragma unroll
+      for (int i = 0; i < PK_PF; ++i) {
+        const int u = PK_PF * g3 + i;
+        const int t = tb + u;
+        R = (u == 0) ? m1[i] : fmax(R, m1[i]);
+        cur[u] = m1[i];
+        if (v[i] == m1[i]) fc |= 1u << u;
+        const double m2 = (u < 20) ? fmax(prevS[(u + 1) % 21], R) : R;
+        // centre frame t - 10: position u-10 of the current block or u+11 of the previous one
+        bool cand;
+        if (u >= 10) cand = ((fc >> ((u + 11) % 21)) & 1u) && cur[(u + 11) % 21] == m2;
+        else cand = ((fp >> ((u + 11) % 21)) & 1u) && ((sp >> ((u + 11) % 21)) & 1u) && prevS[(u + 11) % 21] == m2;
+        const int tc = t - 10;
+        const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
+        bool pk = is_out && in_seg && cand;
+        if (pk) pk = POWER ? (10.0 * log10(m2) > amp_min) : (m2 > amp_min);
+        const unsigned long long bal = __ballot(pk);
+        if (in_seg && lane == 0)
+          mask[((uint64_t)(sg.gframe0 + tc) * n_slabs + slab) * 4 + wave] = bal;
+        if (u == 20) {  // block complete: suffix maxima + "is the suffix max" flags
+          fp = fc;
+          fc = 0;
+          sp = 1u << 20;
+          prevS[20] = cur[20];
+#pragma unroll
+          for (int k = 19; k >= 0; --k) {
+            if (cur[k] >= prevS[k + 1]) sp |= 1u << k;
+            prevS[k] = fmax(cur[k], prevS[k + 1]);
+          }
+        }
+      }
     }
   }
 }
@@ -376,7 +427,8 @@ __global__ void transpose_db_kernel(const double* __restrict__ in, uint32_t stri
   const uint32_t bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: bins, by: frames
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     uint32_t f = by + r, b = bx + threadIdx.x;
-    tile[r][threadIdx.x] = (f < F && b < n_bins) ? in[(uint64_t)f * stride + b] : 0.0;
+    // the staged value is power with zeros stored as 1.0: 10*log10 gives the reference's dB (0 dB for zeros)
+    tile[r][threadIdx.x] = (f < F && b < n_bins) ? 10.0 * log10(in[(uint64_t)f * stride + b]) : 0.0;
   }
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -419,7 +471,7 @@ struct sub_batch {
 static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t n_clips,
                                 std::vector<sub_batch>& out) {
   uint64_t max_frames = ctx->ws_limit / ((uint64_t)DB_STRIDE * 8);
-  if (max_frames > (1u << 19)) max_frames = 1u << 19;  // keeps every per-sub-batch count < 2^32
+  if (max_frames > (1u << 20)) max_frames = 1u << 20;  // mask words, peaks < 2^32 (hash count checked per sub-batch)
   if (max_frames < 64) max_frames = 64;
   sub_batch cur{0, 0, 0};
   for (uint32_t c = 0; c < n_clips; ++c) {
@@ -516,14 +568,14 @@ static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
   uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * 3;
   if (grid > frames) grid = frames;
-  hipLaunchKernelGGL(stft_psd_db_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(stft_psd_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
 
 // peaks of a frame-major dB buffer -> device peak list (ws PEAK_F / PEAK_T) + per-clip offsets (ws PEAK_CLIP)
 static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, uint32_t n_bins, const sub_dev& sd,
-                         uint32_t nc, uint32_t frames, double amp_min, uint16_t** d_pf, uint32_t** d_pt,
+                         uint32_t nc, uint32_t frames, double amp_min, bool is_power, uint16_t** d_pf, uint32_t** d_pt,
                          uint32_t** d_pcoff, uint32_t* n_peaks) {
   const uint32_t n_slabs = (n_bins + PK_SW - 1) / PK_SW;
   const uint64_t n_words = (uint64_t)frames * n_slabs * 4;
@@ -533,8 +585,12 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &d_tot));
   {
     shz_prof_scope ps(ctx, 1);
-    hipLaunchKernelGGL(peak_pick_kernel, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride, n_bins,
-                       sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
+    if (is_power)
+      hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
+                         n_bins, sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
+    else
+      hipLaunchKernelGGL(peak_pick_kernel<false>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
+                         n_bins, sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
     SHZ_HIP(ctx, hipGetLastError());
   }
   uint64_t tot = 0;
@@ -674,7 +730,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     SHZ_TRY(launch_stft(ctx, d_pcm, sd, nc, sb.frames, fs, (double*)d_db));
     uint16_t* d_pf;
     uint32_t *d_pt, *d_pcoff, n_peaks;
-    SHZ_TRY(run_peaks(ctx, (const double*)d_db, DB_STRIDE, SHZ_NBINS, sd, nc, sb.frames, amp_min, &d_pf, &d_pt,
+    SHZ_TRY(run_peaks(ctx, (const double*)d_db, DB_STRIDE, SHZ_NBINS, sd, nc, sb.frames, amp_min, true, &d_pf, &d_pt,
                       &d_pcoff, &n_peaks));
     if (!want_hashes) {
       std::vector<uint32_t> pco(nc + 1);
@@ -691,6 +747,8 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
       total += n_peaks;
       continue;
     }
+    if ((uint64_t)n_peaks * (fan > 1 ? fan - 1 : 0) >= (1ull << 32))
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "sub-batch yields %u peaks; lower the workspace limit so hash counts stay < 2^32", n_peaks);
     // hashes: write straight into the caller's device arrays, or into a staging pair for host output
     uint32_t *d_key, *d_t1;
     uint64_t out_base, dcap;
@@ -775,7 +833,7 @@ extern "C" int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint16_t* d_pf;
   uint32_t *d_pt, *d_pcoff, n_peaks;
-  SHZ_TRY(run_peaks(ctx, (const double*)d_db, stride, n_rows, sd, 1, n_cols, amp_min, &d_pf, &d_pt, &d_pcoff, &n_peaks));
+  SHZ_TRY(run_peaks(ctx, (const double*)d_db, stride, n_rows, sd, 1, n_cols, amp_min, false, &d_pf, &d_pt, &d_pcoff, &n_peaks));
   if (count) *count = n_peaks;
   if (n_peaks > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %u peaks", n_peaks);
   if (!n_peaks) return SHZ_OK;
