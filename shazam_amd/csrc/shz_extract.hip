@@ -20,7 +20,7 @@
 // ======================================================================================
 // K1: stft_psd.  One workgroup (256 threads) per frame, persistent over frames.
 // real 4096-FFT = complex 2048-FFT (Stockham radix 8,8,8,4 through LDS) + split post-pass.
-// LDS: 2048 double2 data (XOR-swizzled index against bank conflicts) + 1025 double2 twiddles.
+// LDS: 2048 double2 data (XOR-swizzled index against bank conflicts) + twiddle tables (1025 + 16 + 128).
 // ======================================================================================
 typedef double2 cplx;
 
@@ -76,42 +76,57 @@ struct stft_args {
 // shz_stft_db for the whole array.  Exact-zero power maps to 1.0 because the reference maps it
 // to 0 dB (__init__.py:241), which keeps its rank against sub-unity cells.
 __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
-  __shared__ cplx lds[2048 + 1025];
+  __shared__ cplx lds[2048 + 1025 + 16 + 128];
   cplx* buf = lds;
-  cplx* tw = lds + 2048;
+  cplx* tw = lds + 2048;          // W4096^k, k in [0,1024]: pass 4 and the post-pass
+  cplx* tw2 = tw + 1025;          // pass 2: [0..8) = W_64^k, [8..16) = W_64^2k   (contiguous: no bank conflicts)
+  cplx* tw3 = tw2 + 16;           // pass 3: [0..64) = W_512^k, [64..128) = W_512^2k
   const int j = threadIdx.x;
   for (int i = j; i < 1025; i += 256) tw[i] = a.tw[i];
+  if (j < 8) { tw2[j] = a.tw[64 * j]; tw2[8 + j] = a.tw[128 * j]; }
+  if (j < 64) { tw3[j] = a.tw[8 * j]; tw3[64 + j] = a.tw[16 * j]; }
   __syncthreads();
   const int sw = (j >> 3) & 7;  // swizzle term of element j + 256 t
 
-  for (uint32_t g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
-    // clip of frame g (uniform binary search over the frame offsets)
-    uint32_t lo = 0, hi = a.n_clips;
+  // the Hann window values this thread multiplies with are the same for every frame: registers
+  double2 ww[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.window + 2 * (j + 256 * t));
+
+  // PCM of a frame as 8 packed sample pairs per thread (lo16 = x[2n], hi16 = x[2n+1], n = j + 256 t).
+  // The loads of frame g + gridDim are issued BEFORE frame g's output stores: vmcnt retires in
+  // order, so loads issued behind the stores would wait for the stores' HBM acknowledgements.
+  int pw[8];
+  auto issue_loads = [&](uint32_t g) {
+    uint32_t lo = 0, hi = a.n_clips;  // clip of frame g (uniform binary search over the frame offsets)
     while (hi - lo > 1) {
       uint32_t mid = (lo + hi) >> 1;
       if (a.clip_foff[mid] <= g) lo = mid; else hi = mid;
     }
-    const uint32_t c = lo;
-    const uint64_t clen = a.clip_len[c];
-    const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[c]) * SHZ_HOP;
-    const int16_t* src = a.pcm + a.clip_soff[c] + s_in_clip;
+    const uint64_t clen = a.clip_len[lo];
+    const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * SHZ_HOP;
+    const int16_t* src = a.pcm + a.clip_soff[lo] + s_in_clip;
     const uint64_t avail = clen > s_in_clip ? clen - s_in_clip : 0;  // samples readable from src
+    if (avail >= SHZ_NFFT && (((uintptr_t)src) & 3) == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pw[t] = reinterpret_cast<const int*>(src)[j + 256 * t];
+    } else {  // odd sample offset, or zero padding of inputs shorter than one window (mlab:268-271)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint64_t n0 = 2 * (uint64_t)(j + 256 * t);
+        const int x0 = n0 < avail ? (int)src[n0] : 0;
+        const int x1 = n0 + 1 < avail ? (int)src[n0 + 1] : 0;
+        pw[t] = (x0 & 0xFFFF) | (x1 << 16);
+      }
+    }
+  };
+  if (blockIdx.x < a.total_frames) issue_loads(blockIdx.x);
 
+  for (uint32_t g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
     cplx v[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int n = j + 256 * t;  // complex index; samples 2n, 2n+1
-      const double2 w = *reinterpret_cast<const double2*>(a.window + 2 * n);
-      double x0, x1;
-      if (avail >= SHZ_NFFT) {
-        x0 = (double)src[2 * n];
-        x1 = (double)src[2 * n + 1];
-      } else {  // zero padding of short inputs (mlab:268-271)
-        x0 = (uint64_t)(2 * n) < avail ? (double)src[2 * n] : 0.0;
-        x1 = (uint64_t)(2 * n + 1) < avail ? (double)src[2 * n + 1] : 0.0;
-      }
-      v[t] = make_double2(x0 * w.x, x1 * w.y);
-    }
+    for (int t = 0; t < 8; ++t)
+      v[t] = make_double2((double)(short)(pw[t] & 0xFFFF) * ww[t].x, (double)(pw[t] >> 16) * ww[t].y);
     // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
     dft8(v);
 #pragma unroll
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
       __syncthreads();
       const int k = j & 7;
-      const cplx w1 = tw[64 * k], w2 = tw[128 * k];
+      const cplx w1 = tw2[k], w2 = tw2[8 + k];
       const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
       v[1] = cmul(v[1], w1);
       v[2] = cmul(v[2], w2);
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
       __syncthreads();
       const int k = j & 63;
-      const cplx w1 = tw[8 * k], w2 = tw[16 * k];
+      const cplx w1 = tw3[k], w2 = tw3[64 + k];
       const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
       v[1] = cmul(v[1], w1);
       v[2] = cmul(v[2], w2);
@@ -181,6 +196,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       }
       __syncthreads();
     }
+    if (g + gridDim.x < a.total_frames) issue_loads(g + gridDim.x);  // in flight across the stores below
     // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale
     double* orow = a.out + (uint64_t)g * DB_STRIDE;
     const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
