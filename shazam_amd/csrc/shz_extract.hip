@@ -241,10 +241,14 @@ struct peak_seg {
   uint32_t t0, t1;   // output frames [t0, t1)
 };
 
+// exact threshold test of the reference, `10*log10(P) > amp_min` (__init__.py:161,241), kept out of
+// line: it runs only for local maxima whose power lies within 1e-9 of the threshold
+__device__ __noinline__ bool db_above(double p, double amp_min) { return 10.0 * log10(p) > amp_min; }
+
 template <bool POWER>
 __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restrict__ A, uint32_t row_stride,
                                                         uint32_t n_bins, const peak_seg* __restrict__ segs,
-                                                        uint32_t n_slabs, double amp_min,
+                                                        uint32_t n_slabs, double amp_min, double p_lo, double p_hi,
                                                         uint64_t* __restrict__ mask) {
   __shared__ double raw[PK_PF][256];   // PK_PF consecutive frames' rows of this slab
   __shared__ double pr2[PK_PF][256];   // pair maxima of the same rows
@@ -324,7 +328,11 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
         const int tc = t - 10;
         const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
         bool pk = is_out && in_seg && cand;
-        if (pk) pk = POWER ? (10.0 * log10(m2) > amp_min) : (m2 > amp_min);
+        if (POWER) {  // power > p_hi: surely above amp_min dB; <= p_lo: surely not; between: exact test
+          if (pk) pk = m2 > p_hi || (m2 > p_lo && db_above(m2, amp_min));
+        } else {
+          pk = pk && (m2 > amp_min);
+        }
         const unsigned long long bal = __ballot(pk);
         if (in_seg && lane == 0)
           mask[((uint64_t)(sg.gframe0 + tc) * n_slabs + slab) * 4 + wave] = bal;
@@ -477,7 +485,7 @@ extern "C" uint32_t shz_frame_count(uint64_t n) {
   return (uint32_t)((n - SHZ_NFFT) / SHZ_HOP + 1);
 }
 
-#define PK_SEG 128  // output frames per peak_pick workgroup
+#define PK_SEG 252  // output frames per peak_pick workgroup (12 blocks of 21)
 
 struct sub_batch {
   uint32_t c0, c1;        // clips [c0, c1)
@@ -603,10 +611,11 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
     shz_prof_scope ps(ctx, 1);
     if (is_power)
       hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
-                         n_bins, sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
+                         n_bins, sd.d_segs, n_slabs, amp_min, pow(10.0, amp_min / 10.0) * (1.0 - 1e-9),
+                         pow(10.0, amp_min / 10.0) * (1.0 + 1e-9), (uint64_t*)d_mask);
     else
       hipLaunchKernelGGL(peak_pick_kernel<false>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
-                         n_bins, sd.d_segs, n_slabs, amp_min, (uint64_t*)d_mask);
+                         n_bins, sd.d_segs, n_slabs, amp_min, 0.0, 0.0, (uint64_t*)d_mask);
     SHZ_HIP(ctx, hipGetLastError());
   }
   uint64_t tot = 0;
