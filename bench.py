@@ -36,6 +36,17 @@ STFT_BYTES_PER_FRAME = 4096 + 2049 * 8   # new PCM read + dB row written (staged
 COMPULSORY_BYTES_PER_FRAME = 4096 + 147  # PCM in + ~18.4 hashes x 8 B out
 
 
+def pmc_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), scaled to this
+    run's frames per launch; None when no profile of that kernel is committed."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+        k = {"stft_psd": "stft_psd_kernel", "peak_pick": "peak_pick_kernel<true>"}[kernel]
+        return prof["kernels"][k]["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000)
+    except Exception:
+        return None
+
+
 def cpu_worker(args):
     seed, clip, n = args
     from oracle import synth, thirdparty_ref
@@ -145,10 +156,10 @@ def main():
     dom_ms, dom_launches = kms[dom]
     frames_per_launch = frames_per_step * a.steps / max(dom_launches, 1)
     avg_ms = dom_ms / max(dom_launches, 1)
-    bytes_per_frame = {"stft_psd_db": STFT_BYTES_PER_FRAME, "peak_pick": 2049 * 8 + 288}.get(dom, STFT_BYTES_PER_FRAME)
+    bytes_per_frame = {"stft_psd": STFT_BYTES_PER_FRAME, "peak_pick": 2049 * 8 + 288}.get(dom, STFT_BYTES_PER_FRAME)
     achieved = frames_per_launch * bytes_per_frame / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch), "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01b_pmc_traffic.json)",
                 "accounting": f"kernel I/O bytes: {bytes_per_frame} B/frame x {frames_per_launch:.0f} frames/launch / "
                               f"{avg_ms:.3f} ms avg launch (HIP events, {dom_launches} launches in the timed region)",
                 "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kms.items()},
@@ -217,6 +228,16 @@ def main():
                         "rows_scanned": st["rows_scanned"], "pairs": st["pairs"],
                         "alg_GBs": (8 * st["rows_scanned"] + 16 * st["distinct_keys"]) / t_match / 1e9}
         qpcm.free()
+        # the same hot path fed from HOST memory (pageable numpy -> hipMemcpy inside the call): PCIe-inclusive rate
+        nh = min(200, nc)
+        host_pcm = pcm.download(np.int16, nh * n_samples)
+        hoff = np.arange(nh + 1, dtype=np.uint64) * n_samples
+        ctx.fingerprint_batch(host_pcm, hoff)
+        t0 = time.perf_counter()
+        ctx.fingerprint_batch(host_pcm, hoff)
+        t_host = time.perf_counter() - t0
+        out["pcie_inclusive"] = {"clips": nh, "audio_s_per_s": nh * n_samples / FS / t_host,
+                                 "note": "host int16 PCM in, host (key32,t1) out, pageable memory; never the headline value"}
         tbl.close()
         if comm:
             comm.close()

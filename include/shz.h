@@ -72,7 +72,7 @@ int32_t shz_set_workspace_limit(shz_ctx* ctx, uint64_t bytes);
 int32_t shz_timer_start(shz_ctx* ctx, int32_t slot);
 int32_t shz_timer_stop(shz_ctx* ctx, int32_t slot, float* elapsed_ms);
 /* per-kernel accumulated device time of the last profiled call (see shz_set_profiling).
- * which: 0 stft_psd_db, 1 peak_pick, 2 peak_expand(+scan), 3 pair_hash(+scan) */
+ * which: 0 stft_psd, 1 peak_pick, 2 peak_expand(+scan), 3 pair_hash(+scan) */
 int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled);
 int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t* launches);
 

@@ -110,7 +110,16 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
     if (avail >= SHZ_NFFT && (((uintptr_t)src) & 3) == 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) pw[t] = reinterpret_cast<const int*>(src)[j + 256 * t];
-    } else {  // odd sample offset, or zero padding of inputs shorter than one window (mlab:268-271)
+    } else if (avail >= SHZ_NFFT) {  // clip starts at an odd sample of the packed PCM buffer
+      int x0[8], x1[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        x0[t] = (int)src[2 * (j + 256 * t)];
+        x1[t] = (int)src[2 * (j + 256 * t) + 1];
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pw[t] = (x0[t] & 0xFFFF) | (x1[t] << 16);
+    } else {  // zero padding of inputs shorter than one window (mlab:268-271)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const uint64_t n0 = 2 * (uint64_t)(j + 256 * t);
