@@ -80,6 +80,78 @@ def cpu_baseline(n_samples, budget_s=15.0):
             "hashes_per_clip": float(np.mean([r[1] for r in res]))}
 
 
+def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elapsed, pcm, out):
+    from shazam_amd import _ffi
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    from shazam_amd import Table
+    tbl = Table(ctx)
+    comm = None
+    if world > 1:
+        ids = [_ffi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = _ffi.Comm(ctx, ids[0], rank, world)
+        comm.barrier()
+    barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    tbl.insert_clips(kbuf, tbuf, hash_off, sid0=1 + rank * nc, device=True)
+    t_ins = time.perf_counter() - t0
+    recv = 0
+    if comm:
+        recv = tbl.allgather(comm)      # RCCL all-gather of every rank's rows + finalize
+    else:
+        tbl.finalize()
+    ctx.sync()
+    barrier()
+    t_build = time.perf_counter() - t0
+    rows, _ = tbl.rows()
+    out["db_build"] = {"rows": int(rows), "songs": world * nc, "seconds_table_only": t_build,
+                       "seconds_incl_fingerprint": t_build + elapsed / a.steps,
+                       "songs_per_second_incl_fingerprint": world * nc / (t_build + elapsed / a.steps),
+                       "allgather_bytes_received": int(recv), "collective": "rccl grouped broadcast (all-gather-v)" if comm else None}
+    # batched recognise: hop-aligned 5 s crops of this rank's own tracks (clean; SNR mixing is a test-side path)
+    nq = min(a.queries, nc)
+    qn = 220500
+    rng = np.random.default_rng(7 + rank)
+    starts = rng.integers(0, (n_samples - qn) // 2048, nq) * 2048
+    qpcm = ctx.alloc(nq * qn * 2)
+    for q in range(nq):   # device-side crop: generate samples [start, start+qn) of clip q
+        _ffi.lib().shz_synth_pcm(ctx.h, 1234, rank * nc + q, 1, qn, 0, 8000, int(starts[q]), _ffi.vp(qpcm.ptr + q * qn * 2))
+    qoff = np.arange(nq + 1, dtype=np.uint64) * qn
+    ctx.sync()
+    t0 = time.perf_counter()
+    k, t1, ho, _ = ctx.fingerprint_batch(qpcm, qoff, pcm_device=True)
+    t_fp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = tbl.match(k, t1, ho, 2)
+    t_match = time.perf_counter() - t0
+    st = tbl.match_stats()
+    correct = int(np.sum((res["nres"] > 0) & (res["sid"][:, 0] == 1 + rank * nc + np.arange(nq)) &
+                         (res["delta"][:, 0] == starts // 2048)))
+    out["match"] = {"queries": nq, "query_seconds": 5.0, "db_rows": int(rows), "ms_per_query_batched": t_match / nq * 1e3,
+                    "qps": nq / t_match, "fingerprint_ms_per_query": t_fp / nq * 1e3, "top1_correct": correct,
+                    "rows_scanned": st["rows_scanned"], "pairs": st["pairs"],
+                    "alg_GBs": (8 * st["rows_scanned"] + 16 * st["distinct_keys"]) / t_match / 1e9}
+    qpcm.free()
+    # the same hot path fed from HOST memory (pageable numpy -> hipMemcpy inside the call): PCIe-inclusive rate
+    nh = min(200, nc)
+    host_pcm = pcm.download(np.int16, nh * n_samples)
+    hoff = np.arange(nh + 1, dtype=np.uint64) * n_samples
+    ctx.fingerprint_batch(host_pcm, hoff)
+    t0 = time.perf_counter()
+    ctx.fingerprint_batch(host_pcm, hoff)
+    t_host = time.perf_counter() - t0
+    out["pcie_inclusive"] = {"clips": nh, "audio_s_per_s": nh * n_samples / FS / t_host,
+                             "note": "host int16 PCM in, host (key32,t1) out, pageable memory; never the headline value"}
+    tbl.close()
+    if comm:
+        comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,7 +187,7 @@ def main():
         cpu = cpu_baseline(n_samples)   # before any HIP call: the Pool forks from a GPU-free process
 
     from shazam_amd import _ffi
-    ctx = _ffi.Context(local)
+    ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", local)))
     info = ctx.device_info()
     nc = a.clips
     frames_per_clip = int(_ffi.lib().shz_frame_count(n_samples))
@@ -177,76 +249,33 @@ def main():
            "x_realtime_per_gpu": value / world, "roofline": roofline}
 
     # ---- extras (outside the timed region) -------------------------------------------------
-    if not a.no_extras:
-        from shazam_amd import Table
-        tbl = Table(ctx)
-        comm = None
-        if world > 1:
-            ids = [_ffi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = _ffi.Comm(ctx, ids[0], rank, world)
-            comm.barrier()
-        barrier()
-        ctx.sync()
-        t0 = time.perf_counter()
-        tbl.insert_clips(kbuf, tbuf, hash_off, sid0=1 + rank * nc, device=True)
-        t_ins = time.perf_counter() - t0
-        recv = 0
-        if comm:
-            recv = tbl.allgather(comm)      # RCCL all-gather of every rank's rows + finalize
-        else:
-            tbl.finalize()
-        ctx.sync()
-        barrier()
-        t_build = time.perf_counter() - t0
-        rows, _ = tbl.rows()
-        out["db_build"] = {"rows": int(rows), "songs": world * nc, "seconds_table_only": t_build,
-                           "seconds_incl_fingerprint": t_build + elapsed / a.steps,
-                           "songs_per_second_incl_fingerprint": world * nc / (t_build + elapsed / a.steps),
-                           "allgather_bytes_received": int(recv), "collective": "rccl grouped broadcast (all-gather-v)" if comm else None}
-        # batched recognise: hop-aligned 5 s crops of this rank's own tracks (clean; SNR mixing is a test-side path)
-        nq = min(a.queries, nc)
-        qn = 220500
-        rng = np.random.default_rng(7 + rank)
-        starts = rng.integers(0, (n_samples - qn) // 2048, nq) * 2048
-        qpcm = ctx.alloc(nq * qn * 2)
-        for q in range(nq):   # device-side crop: generate samples [start, start+qn) of clip q
-            _ffi.lib().shz_synth_pcm(ctx.h, 1234, rank * nc + q, 1, qn, 0, 8000, int(starts[q]), _ffi.vp(qpcm.ptr + q * qn * 2))
-        qoff = np.arange(nq + 1, dtype=np.uint64) * qn
-        ctx.sync()
-        t0 = time.perf_counter()
-        k, t1, ho, _ = ctx.fingerprint_batch(qpcm, qoff, pcm_device=True)
-        t_fp = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        res = tbl.match(k, t1, ho, 2)
-        t_match = time.perf_counter() - t0
-        st = tbl.match_stats()
-        correct = int(np.sum((res["nres"] > 0) & (res["sid"][:, 0] == 1 + rank * nc + np.arange(nq)) &
-                             (res["delta"][:, 0] == starts // 2048)))
-        out["match"] = {"queries": nq, "query_seconds": 5.0, "db_rows": int(rows), "ms_per_query_batched": t_match / nq * 1e3,
-                        "qps": nq / t_match, "fingerprint_ms_per_query": t_fp / nq * 1e3, "top1_correct": correct,
-                        "rows_scanned": st["rows_scanned"], "pairs": st["pairs"],
-                        "alg_GBs": (8 * st["rows_scanned"] + 16 * st["distinct_keys"]) / t_match / 1e9}
-        qpcm.free()
-        # the same hot path fed from HOST memory (pageable numpy -> hipMemcpy inside the call): PCIe-inclusive rate
-        nh = min(200, nc)
-        host_pcm = pcm.download(np.int16, nh * n_samples)
-        hoff = np.arange(nh + 1, dtype=np.uint64) * n_samples
-        ctx.fingerprint_batch(host_pcm, hoff)
-        t0 = time.perf_counter()
-        ctx.fingerprint_batch(host_pcm, hoff)
-        t_host = time.perf_counter() - t0
-        out["pcie_inclusive"] = {"clips": nh, "audio_s_per_s": nh * n_samples / FS / t_host,
-                                 "note": "host int16 PCM in, host (key32,t1) out, pageable memory; never the headline value"}
-        tbl.close()
-        if comm:
-            comm.close()
-
     if cpu is not None:
         out["cpu_baseline"] = cpu
         out["gpu_over_cpu"] = value / cpu["value"]
-    if rank == 0:
-        print(json.dumps(out))
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    # ---- extras (outside the timed region).  A watchdog prints the headline line and exits if the
+    # extras (RCCL init / all-gather on an unknown node) hang, so the measured value is never lost.
+    if not a.no_extras:
+        import threading
+
+        def on_timeout():   # runs in its own thread: a hung RCCL call inside ctypes cannot block it
+            out["extras_error"] = "extras timed out after 240 s"
+            emit()
+            os._exit(0)
+
+        dog = threading.Timer(240.0, on_timeout)
+        dog.daemon = True
+        dog.start()
+        try:
+            extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elapsed, pcm, out)
+        except Exception as e:  # noqa: BLE001 -- extras must never cost the headline number
+            out["extras_error"] = repr(e)
+        dog.cancel()
+    emit()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

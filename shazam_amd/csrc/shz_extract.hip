@@ -129,9 +129,16 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       }
     }
   };
-  if (blockIdx.x < a.total_frames) issue_loads(blockIdx.x);
+  // XCD-aware frame map: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch), so each
+  // group of gridDim/8 workgroups walks ONE contiguous eighth of the frames and the 50 % overlap of
+  // neighbouring frames is served by that XCD's L2 (a speed choice only; any placement is correct).
+  const uint32_t gstep = gridDim.x >> 3;                       // host launches a multiple of 8 workgroups
+  const uint32_t chunk = (a.total_frames + 7) >> 3;
+  const uint32_t g0 = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const uint32_t gend = min(((blockIdx.x & 7) + 1) * chunk, a.total_frames);
+  if (g0 < gend) issue_loads(g0);
 
-  for (uint32_t g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
+  for (uint32_t g = g0; g < gend; g += gstep) {
     cplx v[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       }
       __syncthreads();
     }
-    if (g + gridDim.x < a.total_frames) issue_loads(g + gridDim.x);  // in flight across the stores below
+    if (g + gstep < gend) issue_loads(g + gstep);  // in flight across the stores below
     // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale
     double* orow = a.out + (uint64_t)g * DB_STRIDE;
     const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
@@ -601,6 +608,7 @@ static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
   uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * 3;
   if (grid > frames) grid = frames;
+  grid = (grid + 7) & ~7u;  // multiple of 8: see the XCD-aware frame map in the kernel
   hipLaunchKernelGGL(stft_psd_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
