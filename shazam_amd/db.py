@@ -158,6 +158,43 @@ class HipFingerprintDB:
         self.finalize()
         return self.table.match(key32, q_off, query_off, topn)
 
+    # ---- dump / load / export (checkpoint-resume of a long build) ----------------------
+    def save(self, path: str):
+        """Write the table (sorted unique rows) and the songs dict to one .npz file."""
+        self.finalize()
+        k, s, o = self.table.export()
+        sids = sorted(self.songs)
+        np.savez(path, key32=k, song_id=s, offset=o, next_sid=np.int64(self._next_sid),
+                 songs_sid=np.array(sids, np.int64),
+                 songs_name=np.array([self.songs[i]["song_name"] for i in sids], dtype=object).astype("U"),
+                 songs_sha1=np.array([self.songs[i]["file_sha1"] for i in sids], dtype=object).astype("U"),
+                 songs_total=np.array([self.songs[i]["total_hashes"] for i in sids], np.int64),
+                 songs_fp=np.array([self.songs[i]["fingerprinted"] for i in sids], np.int8))
+
+    @classmethod
+    def load(cls, path: str, **options):
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+        db = cls(**options)
+        if len(z["key32"]):
+            db.table.insert(z["key32"], z["song_id"], z["offset"])
+        db.table.finalize()
+        for sid, name, sha, tot, fp in zip(z["songs_sid"].tolist(), z["songs_name"].tolist(), z["songs_sha1"].tolist(),
+                                           z["songs_total"].tolist(), z["songs_fp"].tolist()):
+            db.songs[sid] = {"song_name": name, "file_sha1": sha, "total_hashes": int(tot), "fingerprinted": int(fp),
+                             "date_created": datetime.now()}
+        db._next_sid = int(z["next_sid"])
+        return db
+
+    def export_mysql_rows(self, chunk: int = 1 << 20):
+        """Yield (song_id, hash10 bytes, offset) in table order: the VALUES of the reference's
+        INSERT_FINGERPRINT after UNHEX (mysql_database.py:62-68), BINARY(10) digests from the GPU."""
+        self.finalize()
+        k, s, o = self.table.export()
+        for i in range(0, len(k), chunk):
+            dig = self.ctx.sha1_prefix(k[i:i + chunk])
+            for j in range(len(dig)):
+                yield int(s[i + j]), dig[j].tobytes(), int(o[i + j])
+
     def num_fingerprints(self) -> int:
         self.finalize()
         return self.table.rows()[0]

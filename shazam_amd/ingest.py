@@ -73,3 +73,108 @@ class ShardedBuilder:
         else:
             self.db.finalize()
         return {"tracks": hi - lo, "hashes": n_hashes, "bytes_received": recv, "rows": self.db.table.rows()[0]}
+
+
+# ---------------------------------------------------------------------------------------------
+# Ingest orchestration: fingerprint_directory with the reference's semantics
+# (__init__.py:248-268, 286-393, 407-415), batched for the GPU.  mp3 decoding stays external
+# (pydub/ffmpeg are not part of the hot path); WAV goes through the stdlib.
+# ---------------------------------------------------------------------------------------------
+import fnmatch
+import os
+import wave
+from hashlib import sha1
+
+
+def unique_hash(file_path: str, block_size: int = 2 ** 20) -> str:
+    """SHA-1 of the file bytes, upper-case hex (__init__.py:305-323)."""
+    s = sha1()
+    with open(file_path, "rb") as f:
+        while True:
+            buf = f.read(block_size)
+            if not buf:
+                break
+            s.update(buf)
+    return s.hexdigest().upper()
+
+
+def find_files(path: str, extensions):
+    """(path, extension) of every file under ``path`` with one of the extensions (__init__.py:286-303)."""
+    extensions = [e.replace(".", "") for e in extensions]
+    results = []
+    for dirpath, _dirnames, files in os.walk(path):
+        for extension in extensions:
+            for f in fnmatch.filter(files, f"*.{extension}"):
+                results.append((os.path.join(dirpath, f), extension))
+    return results
+
+
+def read(file_name: str, limit: int = None):
+    """(channels, frame_rate, file_sha1) like read() (__init__.py:70-113) for 16-bit PCM WAV files:
+    channels de-interleaved as data[chn::n_channels], optional limit in seconds from the start."""
+    with wave.open(file_name, "rb") as w:
+        if w.getsampwidth() != 2:
+            raise NotImplementedError(f"{file_name}: only 16-bit PCM WAV is read here ({8 * w.getsampwidth()}-bit given)")
+        n = w.getnframes()
+        if limit:
+            n = min(n, int(limit * w.getframerate()))
+        data = np.frombuffer(w.readframes(n), np.int16)
+        nch, fr = w.getnchannels(), w.getframerate()
+    return [np.ascontiguousarray(data[c::nch]) for c in range(nch)], fr, unique_hash(file_name)
+
+
+def load_fingerprinted_audio_hashes(db, songhashes_set=None):
+    """file SHA-1s of every fingerprinted song (__init__.py:407-415; FIELD_FILE_SHA1 = column 2)."""
+    songhashes_set = set() if songhashes_set is None else songhashes_set
+    for song in db.get_songs():
+        songhashes_set.add(song[2])
+    return songhashes_set
+
+
+def fingerprint_directory(path: str, extensions, db, songhashes_set=None, limit: int = None, batch_files: int = 64,
+                          reader=read):
+    """Fingerprint every matching file not yet in ``db`` (by file SHA-1) and insert it, with the
+    reference's bookkeeping (__init__.py:325-393): per file the fingerprints of all channels are
+    united as a set (:254-265), ``insert_song(name, sha1, len(set))`` (:381), ``insert_hashes``,
+    ``set_song_fingerprinted``.  Files are decoded on the host and fingerprinted ``batch_files`` at a
+    time in one GPU batch instead of one process-pool task per file.  Returns [(song_id, name, n)]."""
+    import shazam_amd as S
+    songhashes_set = load_fingerprinted_audio_hashes(db, songhashes_set)
+    todo = []
+    for filename, _ in find_files(path, extensions):
+        if unique_hash(filename) in songhashes_set:   # don't refingerprint (__init__.py:346-348)
+            continue
+        todo.append(filename)
+    done = []
+    for b0 in range(0, len(todo), batch_files):
+        files, chans, owner, rates = todo[b0:b0 + batch_files], [], [], []
+        meta = []
+        for fi, fn in enumerate(files):
+            try:
+                channels, fs, file_hash = reader(fn, limit)
+            except Exception as e:  # the reference prints and skips failed files (__init__.py:373-376)
+                print(f"Failed fingerprinting {fn}: {e}")
+                continue
+            meta.append((fi, fn, fs, file_hash, len(chans), len(channels)))
+            chans.extend(channels)
+            rates.append(fs)
+        # one GPU batch per distinct sample rate (Fs only scales the spectrogram; hashes do not depend on it)
+        for fs in sorted(set(rates)):
+            sel = [m for m in meta if m[2] == fs]
+            flat = [c for m in sel for c in chans[m[4]:m[4] + m[5]]]
+            if not flat:
+                continue
+            k, t1, ho = S.fingerprint_batch(flat, Fs=fs, ctx=db.ctx)
+            pos = 0
+            for (_fi, fn, _fs, file_hash, _c0, nch) in sel:
+                lo, hi = int(ho[pos]), int(ho[pos + nch])
+                pos += nch
+                pairs = np.unique((k[lo:hi].astype(np.uint64) << np.uint64(32)) | t1[lo:hi].astype(np.uint64))
+                song_name = os.path.splitext(os.path.basename(fn))[0]
+                sid = db.insert_song(song_name, file_hash, len(pairs))
+                db.insert_keys(sid, (pairs >> np.uint64(32)).astype(np.uint32), (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+                db.set_song_fingerprinted(sid)
+                songhashes_set.add(file_hash)
+                done.append((sid, song_name, len(pairs)))
+    db.finalize()
+    return done
