@@ -82,6 +82,13 @@ int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t
 int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
                       int32_t tone_amp, int32_t noise_amp, uint64_t start_sample, int16_t* dev_out);
 
+/* Query preparation (bench / tests): exact sum of squares of each clip (device PCM, clip-major, equal
+ * lengths) to HOST, and out = clip(rint(sig + scale[c] * noise)) on the device: the digital form of
+ * get_noise_from_sound + sf.write (recognizer_test.py:426-435, 557); twin: oracle/synth.mix_query. */
+int32_t shz_sumsq_i16(shz_ctx* ctx, const int16_t* dev_pcm, uint32_t n_clips, uint64_t n_samples, uint64_t* out_host);
+int32_t shz_mix_i16(shz_ctx* ctx, const int16_t* dev_sig, const int16_t* dev_noise, uint32_t n_clips,
+                    uint64_t n_samples, const double* scale_host, int16_t* dev_out);
+
 /* ---- extraction --------------------------------------------------------------------- */
 /* Frames mlab produces for n_samples (mlab.specgram via __init__.py:232-237). */
 uint32_t shz_frame_count(uint64_t n_samples);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "shz_set_profiling": (C.c_int32, [vp, C.c_int32]),
     "shz_get_kernel_ms": (C.c_int32, [vp, C.c_int32, C.POINTER(C.c_float), u32p]),
     "shz_synth_pcm": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, vp]),
+    "shz_sumsq_i16": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint64, u64p]),
+    "shz_mix_i16": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, f64p, vp]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -205,6 +207,23 @@ class Context:
             self.check(lib().shz_synth_pcm(self.h, seed, clip0 + done, k, n_samples, tone_amp, noise_amp, start,
                                            vp(out.ptr + done * n_samples * 2)))
             done += k
+        return out
+
+    def mix_snr(self, sig: "DevBuf", noise: "DevBuf", n_clips: int, n_samples: int, snr_db: float, out: "DevBuf" = None) -> "DevBuf":
+        """Per clip: noise scaled to the requested SNR (recognizer_test.py:426-435) and added; int16 out."""
+        import math
+        ss, sn = np.zeros(n_clips, np.uint64), np.zeros(n_clips, np.uint64)
+        self.check(lib().shz_sumsq_i16(self.h, ptr(sig), n_clips, n_samples, ss.ctypes.data_as(u64p)))
+        self.check(lib().shz_sumsq_i16(self.h, ptr(noise), n_clips, n_samples, sn.ctypes.data_as(u64p)))
+        scale = np.empty(n_clips, np.float64)
+        for c in range(n_clips):   # the reference's formula, evaluated exactly like oracle/synth.mix_query
+            rms_s = math.sqrt(float(ss[c]) / n_samples)
+            rms_n = math.sqrt(rms_s ** 2 / (pow(10, snr_db / 10)))
+            rms_cur = math.sqrt(float(sn[c]) / n_samples)
+            scale[c] = (rms_n / rms_cur) if rms_cur > 0 else 1.0
+        if out is None:
+            out = self.alloc(n_clips * n_samples * 2)
+        self.check(lib().shz_mix_i16(self.h, ptr(sig), ptr(noise), n_clips, n_samples, scale.ctypes.data_as(f64p), ptr(out)))
         return out
 
     # ---- extraction ---------------------------------------------------------------------------

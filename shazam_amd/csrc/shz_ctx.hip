@@ -301,3 +301,69 @@ extern "C" int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, ui
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Query preparation on the device (bench / tests): exact integer sum of squares per clip and
+// signal + scale * noise re-quantised to int16 -- the digital form of the reference's noise
+// mixing (recognizer_test.py:426-435, 557).  The scale itself is computed on the host from the
+// exact sums with the reference's formula, so the numpy twin (oracle/synth.mix_query) and this
+// path agree bit for bit.
+__global__ __launch_bounds__(256) void sumsq_i16_kernel(const int16_t* __restrict__ x, uint64_t n_samples,
+                                                        unsigned long long* __restrict__ out) {
+  const int16_t* src = x + (uint64_t)blockIdx.y * n_samples;
+  unsigned long long s = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
+    const long long v = src[i];
+    s += (unsigned long long)(v * v);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor((long long)s, d, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out + blockIdx.y, s);
+}
+
+__global__ __launch_bounds__(256) void mix_i16_kernel(const int16_t* __restrict__ sig, const int16_t* __restrict__ noise,
+                                                      uint64_t n_samples, const double* __restrict__ scale,
+                                                      int16_t* __restrict__ out) {
+  const uint64_t base = (uint64_t)blockIdx.y * n_samples;
+  const double sc = scale[blockIdx.y];
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
+    double v = rint((double)sig[base + i] + (double)noise[base + i] * sc);
+    v = v < -32768.0 ? -32768.0 : (v > 32767.0 ? 32767.0 : v);
+    out[base + i] = (int16_t)v;
+  }
+}
+
+extern "C" int32_t shz_sumsq_i16(shz_ctx* ctx, const int16_t* dev_pcm, uint32_t n_clips, uint64_t n_samples,
+                                 uint64_t* out_host) {
+  if (!ctx || !dev_pcm || !out_host) return SHZ_E_INVALID;
+  if (n_clips == 0) return SHZ_OK;
+  if (n_clips > 65535) SHZ_FAIL(ctx, SHZ_E_INVALID, "at most 65535 clips per call");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void* d;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, 8ull * n_clips, &d));
+  SHZ_HIP(ctx, hipMemsetAsync(d, 0, 8ull * n_clips, ctx->stream));
+  uint64_t per = (n_samples + 255) / 256;
+  dim3 grid((unsigned)(per > 64 ? 64 : (per ? per : 1)), n_clips);
+  hipLaunchKernelGGL(sumsq_i16_kernel, grid, dim3(256), 0, ctx->stream, dev_pcm, n_samples, (unsigned long long*)d);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipMemcpyAsync(out_host, d, 8ull * n_clips, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_mix_i16(shz_ctx* ctx, const int16_t* dev_sig, const int16_t* dev_noise, uint32_t n_clips,
+                               uint64_t n_samples, const double* scale_host, int16_t* dev_out) {
+  if (!ctx || !dev_sig || !dev_noise || !scale_host || !dev_out) return SHZ_E_INVALID;
+  if (n_clips == 0 || n_samples == 0) return SHZ_OK;
+  if (n_clips > 65535) SHZ_FAIL(ctx, SHZ_E_INVALID, "at most 65535 clips per call");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void* d;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, 8ull * n_clips, &d));
+  SHZ_HIP(ctx, hipMemcpyAsync(d, scale_host, 8ull * n_clips, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t per = (n_samples + 255) / 256;
+  dim3 grid((unsigned)(per > 64 ? 64 : per), n_clips);
+  hipLaunchKernelGGL(mix_i16_kernel, grid, dim3(256), 0, ctx->stream, dev_sig, dev_noise, n_samples, (const double*)d, dev_out);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}

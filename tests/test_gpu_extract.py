@@ -196,3 +196,20 @@ def test_full_size_properties(ctx):
     for c in range(nc):
         assert np.all(np.diff(t1[ho[c]:ho[c + 1]].astype(np.int64)) >= 0)
     pcm.free()
+
+
+def test_device_snr_mix_matches_twin(ctx):
+    """shz_sumsq_i16 + shz_mix_i16 (query preparation) == oracle/synth.mix_query bit for bit."""
+    from oracle import synth
+    n, nc = 30011, 4
+    sig = ctx.synth_pcm(5, 0, nc, n, 4000, 1500)
+    noi = ctx.synth_pcm(6, 10, nc, n, 0, 8000)
+    for snr in (0.0, 10.0, -3.5):
+        out = ctx.mix_snr(sig, noi, nc, n, snr)
+        got = out.download(np.int16, nc * n).reshape(nc, n)
+        for c in range(nc):
+            want = synth.mix_query(synth.synth_clip(5, c, n, 4000, 1500), synth.synth_clip(6, 10 + c, n, 0, 8000), snr)
+            assert np.array_equal(got[c], want), (snr, c)
+        out.free()
+    sig.free()
+    noi.free()
