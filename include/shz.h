@@ -132,6 +132,12 @@ int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
  * mysql_database.py:48).  key32: host or device (SHZ_IN_DEVICE); out10: host [n][10]. */
 int32_t shz_sha1_prefix(shz_ctx* ctx, const uint32_t* key32, uint64_t n, uint32_t flags, uint8_t* out10);
 
+/* Inverse of the above for hashes that arrive as hex/BINARY(10) from outside (a MySQL dump, another
+ * process): the preimage space is only 2049 x 2049 x 201 strings, so the GPU hashes all of it and
+ * looks the digests up.  digests10: host [n][10]; key32_out: host [n], 0xFFFFFFFF where no preimage
+ * exists.  Lets insert_hashes / SELECT_MULTIPLE (mysql_database.py:62-68, 82-86) take foreign hashes. */
+int32_t shz_sha1_invert(shz_ctx* ctx, const uint8_t* digests10, uint64_t n, uint32_t* key32_out);
+
 /* ---- fingerprint table (replaces the MySQL fingerprints table, mysql_database.py:46-68) - */
 int32_t shz_table_create(shz_ctx* ctx, shz_table** out);
 int32_t shz_table_destroy(shz_table* t);

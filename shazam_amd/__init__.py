@@ -93,12 +93,38 @@ def hex_of_keys(ctx: Context, key32: np.ndarray) -> list:
     return [hexes[i] for i in inv.tolist()]
 
 
+def keys_of_hexes(hexes, ctx: Context = None, strict: bool = True) -> np.ndarray:
+    """key32 of hex hashes.  Hashes this process produced come from the cache; any other (a MySQL
+    dump, another process) is inverted on the GPU by hashing the whole 8.4e8-string preimage space
+    (shz_sha1_invert).  Raises KeyError for strings that are not a hash of any (f1, f2, dt)."""
+    hexes = [h.lower() for h in hexes]
+    out = np.empty(len(hexes), np.uint32)
+    missing = []
+    for i, h in enumerate(hexes):
+        k = _HEX2KEY.get(h)
+        if k is None:
+            missing.append(i)
+        else:
+            out[i] = k
+    if missing:
+        uniq = sorted({hexes[i] for i in missing})
+        try:
+            dig = np.frombuffer(bytes.fromhex("".join(uniq)), np.uint8).reshape(-1, 10)
+        except ValueError:
+            raise KeyError("hashes must be 20 hex characters (FINGERPRINT_REDUCTION, __init__.py:51)")
+        keys = (ctx or get_context()).sha1_invert(dig)
+        bad = [u for u, k in zip(uniq, keys.tolist()) if k == 0xFFFFFFFF]
+        if bad and strict:
+            raise KeyError(f"{len(bad)} hash(es) are not sha1(f1|f2|dt)[:20] of any peak pair, e.g. {bad[0]!r}")
+        found = dict(zip(uniq, keys.tolist()))
+        _HEX2KEY.update((u, k) for u, k in found.items() if k != 0xFFFFFFFF)
+        for i in missing:
+            out[i] = found[hexes[i]]   # 0xFFFFFFFF (matches no table row) for non-hashes when not strict
+    return out
+
+
 def key_of_hex(hexstr: str) -> int:
-    k = _HEX2KEY.get(hexstr.lower())
-    if k is None:
-        raise KeyError(f"hash {hexstr!r} was not produced by shazam_amd.fingerprint() in this process; "
-                       "use the key32 API (fingerprint_batch / HipFingerprintDB.insert_keys) across processes")
-    return k
+    return int(keys_of_hexes([hexstr])[0])
 
 
 def _as_pcm(channel_samples) -> np.ndarray:

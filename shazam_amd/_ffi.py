@@ -46,6 +46,7 @@ SIGNATURES = {
     "shz_fingerprint_batch": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32,
                                           vp, vp, u64p, C.c_uint64, u64p]),
     "shz_sha1_prefix": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "shz_sha1_invert": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "shz_table_create": (C.c_int32, [vp, C.POINTER(vp)]),
     "shz_table_destroy": (C.c_int32, [vp]),
     "shz_table_insert": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, C.c_uint32]),
@@ -323,6 +324,17 @@ class Context:
         out = np.empty((int(n), 10), np.uint8)
         self.check(lib().shz_sha1_prefix(self.h, ptr(key32), int(n), IN_DEVICE if device else 0, ptr(out)))
         return out
+
+
+def _sha1_invert(self, digests10: np.ndarray) -> np.ndarray:
+    """key32 of each 10-byte digest (0xFFFFFFFF where none): brute force over the preimage space on the GPU."""
+    d = np.ascontiguousarray(digests10, np.uint8).reshape(-1, 10)
+    out = np.empty(len(d), np.uint32)
+    self.check(lib().shz_sha1_invert(self.h, ptr(d), len(d), ptr(out)))
+    return out
+
+
+Context.sha1_invert = _sha1_invert
 
 
 class Table:

@@ -15,7 +15,7 @@ from datetime import datetime
 import numpy as np
 
 from . import _ffi
-from . import get_context, hex_of_keys, key_of_hex
+from . import get_context, hex_of_keys, keys_of_hexes
 
 
 class _Cursor:
@@ -115,7 +115,7 @@ class HipFingerprintDB:
 
     # ---- fingerprints table (device) -------------------------------------------------------------
     def _insert_rows(self, sids, hexes, offsets):
-        keys = np.fromiter((key_of_hex(h) for h in hexes), np.uint32, len(hexes))
+        keys = keys_of_hexes(hexes, self.ctx)
         self.table.insert(keys, np.asarray(sids, np.uint32), np.asarray([int(o) for o in offsets], np.uint32))
         self._dirty = True
 
@@ -142,15 +142,9 @@ class HipFingerprintDB:
 
     def _select_multiple(self, hex_values):
         self.finalize()
-        keys = []
-        for h in hex_values:
-            try:
-                keys.append(key_of_hex(h))
-            except KeyError:
-                pass  # a hash this process never produced cannot be in the table either
-        if not keys:
+        if not hex_values:
             return []
-        k, s, o = self.table.lookup(np.asarray(keys, np.uint32))
+        k, s, o = self.table.lookup(keys_of_hexes(hex_values, self.ctx, strict=False))
         hexes = hex_of_keys(self.ctx, k)
         return [(h.upper(), int(a), int(b)) for h, a, b in zip(hexes, s.tolist(), o.tolist())]  # HEX() upper-cases
 
