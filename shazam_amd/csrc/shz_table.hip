@@ -48,15 +48,15 @@ __global__ void tbl_expand_clips_kernel(const uint32_t* __restrict__ key32, cons
 __global__ void tbl_compose_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
                                    const uint32_t* __restrict__ off, uint64_t n, uint64_t dst0, uint64_t* __restrict__ k,
                                    uint32_t* __restrict__ v, uint32_t* __restrict__ maxes) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride: a bounded number of workgroups so the two atomicMax words see few, not millions of, updates
   uint32_t s = 0, o = 0;
-  if (i < n) {
-    s = sid[i];
-    o = off[i];
-    k[dst0 + i] = ((uint64_t)s << 32) | o;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t si = sid[i], oi = off[i];
+    k[dst0 + i] = ((uint64_t)si << 32) | oi;
     v[dst0 + i] = key[i];
+    s = max(s, si);
+    o = max(o, oi);
   }
-  // wave max then one atomic per wave
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     s = max(s, (uint32_t)__shfl_xor((int)s, d, 64));
@@ -113,6 +113,50 @@ __global__ void tbl_count_sid_kernel(const uint32_t* __restrict__ sid, uint64_t 
   const bool hit = i < n && sid[i] == want;
   const unsigned long long b = __ballot(hit);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
+
+// fast path of finalize: when song-id and offset bits fit beside the 32 key bits, a row is ONE u64
+// (key | sid | off) and the whole order is a single payload-free radix sort
+__global__ void tbl_max_kernel(const uint32_t* __restrict__ sid, const uint32_t* __restrict__ off, uint64_t n,
+                               uint32_t* __restrict__ maxes) {
+  uint32_t s = 0, o = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    s = max(s, sid[i]);
+    o = max(o, off[i]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s = max(s, (uint32_t)__shfl_xor((int)s, d, 64));
+    o = max(o, (uint32_t)__shfl_xor((int)o, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&maxes[0], s);
+    atomicMax(&maxes[1], o);
+  }
+}
+
+__global__ void tbl_compose1_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
+                                    const uint32_t* __restrict__ off, uint64_t n, uint64_t dst0, int sb, int ob,
+                                    uint64_t* __restrict__ c) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    c[dst0 + i] = ((uint64_t)key[i] << (sb + ob)) | ((uint64_t)sid[i] << ob) | off[i];
+}
+
+__global__ void tbl_uniq1_flag_kernel(const uint64_t* __restrict__ c, uint64_t n, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || c[i] != c[i - 1]) ? 1u : 0u;
+}
+
+__global__ void tbl_compact1_kernel(const uint64_t* __restrict__ c, const uint32_t* __restrict__ flag,
+                                    const uint32_t* __restrict__ pos, uint64_t n, int sb, int ob,
+                                    uint32_t* __restrict__ okey, uint32_t* __restrict__ osid, uint32_t* __restrict__ ooff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t p = pos[i];
+  const uint64_t v = c[i];
+  okey[p] = (uint32_t)(v >> (sb + ob));
+  osid[p] = (uint32_t)((v >> ob) & ((1ull << sb) - 1));
+  ooff[p] = (uint32_t)(v & ((1ull << ob) - 1));
 }
 
 // ---------------------------------------------------------------------------------------- table API
@@ -223,65 +267,101 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
     return SHZ_OK;
   }
   if (total >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "table limited to < 2^32 rows (have %llu)", (unsigned long long)total);
-  void *k0, *k1, *v0, *v1, *mx, *fl, *ps, *tot;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, total * 8, &k0));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, total * 8, &k1));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, total * 8, &v0));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, total * 8, &v1));
+  void *k0, *k1, *v0 = nullptr, *v1 = nullptr, *mx, *fl, *ps, *tot;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &mx));
   SHZ_HIP(ctx, hipMemsetAsync(mx, 0, 64, ctx->stream));
+  const unsigned gmax = 2048;
   if (t->n)
-    hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream, t->key, t->sid,
-                       t->off, t->n, (uint64_t)0, (uint64_t*)k0, (uint32_t*)v0, (uint32_t*)mx);
+    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, gmax)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)t->sid, (const uint32_t*)t->off, t->n, (uint32_t*)mx);
   if (t->ns)
-    hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream, t->skey,
-                       t->ssid, t->soff, t->ns, t->n, (uint64_t*)k0, (uint32_t*)v0, (uint32_t*)mx);
+    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, gmax)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, (uint32_t*)mx);
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t maxes[2];
   SHZ_HIP(ctx, hipMemcpyAsync(maxes, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->max_sid = maxes[0];
   t->max_off = maxes[1];
-  // 1) stable sort by (sid, off) carrying the key, 2) stable sort by key carrying (sid, off)
-  int sel = 0;
-  uint64_t *ka = (uint64_t*)k0, *kb = (uint64_t*)k1;
-  void *va = v0, *vb = v1;
-  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 0, bits_for(maxes[1]), &sel));
-  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
-  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 32, 32 + bits_for(maxes[0]), &sel));
-  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
-  hipLaunchKernelGGL(tbl_swap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)ka,
-                     (const uint32_t*)va, total, kb, (uint64_t*)vb);
-  SHZ_HIP(ctx, hipGetLastError());
-  std::swap(ka, kb);
-  std::swap(va, vb);
-  SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 8, total, 0, 32, &sel));
-  if (sel) { std::swap(ka, kb); std::swap(va, vb); }
-  // unique + compaction into fresh column arrays
+  const int sb = bits_for(maxes[0]), ob = bits_for(maxes[1]);
+  const bool one_key = sb + ob <= 32;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, total * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, total * 8, &k1));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, total * 4, &fl));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, total * 4, &ps));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
-  hipLaunchKernelGGL(tbl_uniq_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const uint64_t*)ka, (const uint64_t*)va, total, (uint32_t*)fl);
+  int sel = 0;
+  uint64_t *ka = (uint64_t*)k0, *kb = (uint64_t*)k1;
+  void *va = nullptr, *vb = nullptr;
+  if (one_key) {
+    if (t->n)
+      hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, 8192)), dim3(256), 0,
+                         ctx->stream, (const uint32_t*)t->key, (const uint32_t*)t->sid, (const uint32_t*)t->off, t->n,
+                         (uint64_t)0, sb, ob, ka);
+    if (t->ns)
+      hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 8192)), dim3(256), 0,
+                         ctx->stream, (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns,
+                         t->n, sb, ob, ka);
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_TRY(shz_sort_u64(ctx, ka, kb, nullptr, nullptr, 0, total, 0, 32 + sb + ob, &sel));
+    if (sel) std::swap(ka, kb);
+    hipLaunchKernelGGL(tbl_uniq1_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)ka, total, (uint32_t*)fl);
+  } else {
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, total * 8, &v0));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, total * 8, &v1));
+    va = v0;
+    vb = v1;
+    if (t->n)
+      hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, 4096)), dim3(256), 0,
+                         ctx->stream, t->key, t->sid, t->off, t->n, (uint64_t)0, ka, (uint32_t*)va, (uint32_t*)mx);
+    if (t->ns)
+      hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 4096)), dim3(256), 0,
+                         ctx->stream, t->skey, t->ssid, t->soff, t->ns, t->n, ka, (uint32_t*)va, (uint32_t*)mx);
+    SHZ_HIP(ctx, hipGetLastError());
+    // 1) stable sort by (sid, off) carrying the key, 2) stable sort by key carrying (sid, off)
+    SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 0, ob, &sel));
+    if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+    SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 32, 32 + sb, &sel));
+    if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+    hipLaunchKernelGGL(tbl_swap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)ka,
+                       (const uint32_t*)va, total, kb, (uint64_t*)vb);
+    SHZ_HIP(ctx, hipGetLastError());
+    std::swap(ka, kb);
+    std::swap(va, vb);
+    SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 8, total, 0, 32, &sel));
+    if (sel) { std::swap(ka, kb); std::swap(va, vb); }
+    hipLaunchKernelGGL(tbl_uniq_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)ka, (const uint64_t*)va, total, (uint32_t*)fl);
+  }
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, total, (uint64_t*)tot));
   uint64_t nu = 0;
   SHZ_HIP(ctx, hipMemcpyAsync(&nu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // the old columns are dead once composed: free them before allocating the new ones (peak memory)
+  {
+    void* olds[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
+    for (void* p : olds)
+      if (p) SHZ_HIP(ctx, hipFree(p));
+    t->key = t->sid = t->off = t->skey = t->ssid = t->soff = t->bucket = nullptr;
+    t->n = t->ns = t->scap = 0;
+  }
   uint32_t *nk, *nsid, *noff;
   if (hipMalloc(&nk, nu * 4 + 4) != hipSuccess || hipMalloc(&nsid, nu * 4 + 4) != hipSuccess ||
       hipMalloc(&noff, nu * 4 + 4) != hipSuccess)
     SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)nu);
-  hipLaunchKernelGGL(tbl_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const uint64_t*)ka, (const uint64_t*)va, (const uint32_t*)fl, (const uint32_t*)ps, total, nk, nsid,
-                     noff);
+  if (one_key)
+    hipLaunchKernelGGL(tbl_compact1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)ka, (const uint32_t*)fl, (const uint32_t*)ps, total, sb, ob, nk, nsid, noff);
+  else
+    hipLaunchKernelGGL(tbl_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)ka, (const uint64_t*)va, (const uint32_t*)fl, (const uint32_t*)ps, total, nk, nsid,
+                       noff);
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t last_key = 0;
   SHZ_HIP(ctx, hipMemcpyAsync(&last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  void* olds[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
-  for (void* p : olds)
-    if (p) SHZ_HIP(ctx, hipFree(p));
   t->key = nk; t->sid = nsid; t->off = noff;
   t->skey = t->ssid = t->soff = nullptr;
   t->ns = t->scap = 0;
@@ -477,6 +557,7 @@ __global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint3
   }
   const uint32_t o = q_off[h];
   if (o >> QOFF_BITS) atomicOr(err, 1u);
+  atomicMax(err + 1, o);  // largest query offset: the vote key biases deltas by it
   c[i] = ((uint64_t)lo << QIDX_SHIFT) | ((uint64_t)key32[h] << QKEY_SHIFT) | (o & ((1u << QOFF_BITS) - 1));
 }
 
@@ -560,7 +641,7 @@ __global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu
   npairs[q] = po[lb_g(b)] - po[lb_g(a)];
 }
 
-struct m_bits { int sb, dbits, qb; };
+struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset of the sub-batch: delta + bias >= 0
 
 __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
                                 const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
@@ -580,22 +661,21 @@ __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* 
   const uint64_t e = E[e0 + oi];
   const uint64_t q = e >> QIDX_SHIFT;
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
-  const uint64_t dprime = (uint64_t)toff[row] + (1u << QOFF_BITS) - qo;  // delta + 2^20 > 0
+  const uint64_t dprime = (uint64_t)toff[row] + mb.bias - qo;  // delta + bias >= 0
   v[p] = ((((q << mb.sb) | tsid[row]) << mb.dbits | dprime) << 1) | (oi == 0 ? 1u : 0u);
 }
 
 // one thread per run that opens a (query, sid) group: fold its runs (ascending delta) into
 // (best count, first delta reaching it, dedup rows)
 __global__ void m_group_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs, uint32_t nr, m_bits mb,
-                               uint32_t* __restrict__ g_head, uint32_t* __restrict__ g_cnt,
-                               uint32_t* __restrict__ g_delta, uint32_t* __restrict__ g_dedup) {
+                               uint64_t* __restrict__ g_pack, uint32_t* __restrict__ g_delta,
+                               uint32_t* __restrict__ g_dedup) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nr) return;
   const int gshift = mb.dbits + 1;
   const uint64_t grp = v[rs[r]] >> gshift;
   const bool head = r == 0 || (v[rs[r - 1]] >> gshift) != grp;
-  g_head[r] = head ? 1u : 0u;
-  if (!head) return;
+  if (!head) { g_pack[r] = 0; return; }   // 0 never wins: a real group has count >= 1
   const uint64_t dmask = (1ull << mb.dbits) - 1;
   uint32_t best = 0, bestd = 0, cur = 0, dedup = 0;
   uint64_t curd = ~0ull;
@@ -613,23 +693,25 @@ __global__ void m_group_kernel(const uint64_t* __restrict__ v, const uint32_t* _
     if (val & 1) dedup += len;
   }
   if (cur > best) { best = cur; bestd = (uint32_t)curd; }
-  g_cnt[r] = best;
+  const uint32_t sid = (uint32_t)(grp & ((1ull << mb.sb) - 1));
+  g_pack[r] = ((uint64_t)best << 32) | (0xFFFFFFFFu - sid);   // rank: count desc, then sid asc
   g_delta[r] = bestd;
   g_dedup[r] = dedup;
 }
 
-// one wave per query: top-n groups by (count desc, sid asc)
-__global__ __launch_bounds__(64) void m_topn_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
-                                                    uint32_t nr, m_bits mb, const uint32_t* __restrict__ g_head,
-                                                    const uint32_t* __restrict__ g_cnt,
-                                                    const uint32_t* __restrict__ g_delta,
-                                                    const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
-                                                    uint32_t* __restrict__ out_sid, int32_t* __restrict__ out_delta,
-                                                    uint32_t* __restrict__ out_aligned, uint32_t* __restrict__ out_dedup,
-                                                    uint32_t* __restrict__ out_nres) {
+// one workgroup per query: top-n groups by (count desc, sid asc) over the packed group summaries
+__global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
+                                                     uint32_t nr, m_bits mb, const uint64_t* __restrict__ g_pack,
+                                                     const uint32_t* __restrict__ g_delta,
+                                                     const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
+                                                     uint32_t* __restrict__ out_sid, int32_t* __restrict__ out_delta,
+                                                     uint32_t* __restrict__ out_aligned, uint32_t* __restrict__ out_dedup,
+                                                     uint32_t* __restrict__ out_nres) {
+  __shared__ uint64_t s_best[4];
+  __shared__ uint32_t s_r[4];
   const uint32_t q = blockIdx.x;
   if (q >= nq) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qshift = mb.sb + mb.dbits + 1;
   auto lb = [&](uint64_t target) {  // first run whose query index >= target
     uint32_t l = 0, h = nr;
@@ -637,36 +719,40 @@ __global__ __launch_bounds__(64) void m_topn_kernel(const uint64_t* __restrict__
     return l;
   };
   const uint32_t r0 = lb(q), r1 = lb((uint64_t)q + 1);
-  const uint64_t smask = (1ull << mb.sb) - 1;
   uint64_t prev = ~0ull;  // packed rank of the previous winner; candidates must rank strictly below it
   uint32_t found = 0;
   for (uint32_t n = 0; n < topn; ++n) {
     uint64_t best = 0;
     uint32_t bestr = 0xFFFFFFFFu;
-    for (uint32_t r = r0 + lane; r < r1; r += 64) {
-      if (!g_head[r]) continue;
-      const uint32_t sid = (uint32_t)((v[rs[r]] >> (mb.dbits + 1)) & smask);
-      const uint64_t packed = ((uint64_t)g_cnt[r] << 32) | (0xFFFFFFFFu - sid);
-      if (packed < prev && (bestr == 0xFFFFFFFFu || packed > best)) { best = packed; bestr = r; }
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
+      const uint64_t packed = g_pack[r];
+      if (packed < prev && packed > best) { best = packed; bestr = r; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       const uint64_t ob = (uint64_t)__shfl_xor((long long)best, d, 64);
       const uint32_t orr = (uint32_t)__shfl_xor((int)bestr, d, 64);
-      if (orr != 0xFFFFFFFFu && (bestr == 0xFFFFFFFFu || ob > best)) { best = ob; bestr = orr; }
+      if (ob > best) { best = ob; bestr = orr; }
     }
-    if (bestr == 0xFFFFFFFFu) break;  // uniform after the butterfly
-    if (lane == 0) {
+    if (lane == 0) { s_best[wave] = best; s_r[wave] = bestr; }
+    __syncthreads();
+    best = s_best[0]; bestr = s_r[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_best[w] > best) { best = s_best[w]; bestr = s_r[w]; }
+    __syncthreads();
+    if (best == 0) break;  // uniform
+    if (threadIdx.x == 0) {
       const uint64_t o = (uint64_t)q * topn + n;
       out_sid[o] = 0xFFFFFFFFu - (uint32_t)best;
       out_aligned[o] = (uint32_t)(best >> 32);
-      out_delta[o] = (int32_t)((int64_t)g_delta[bestr] - (int64_t)(1u << QOFF_BITS));
+      out_delta[o] = (int32_t)((int64_t)g_delta[bestr] - (int64_t)mb.bias);
       out_dedup[o] = g_dedup[bestr];
     }
     prev = best;
     ++found;
   }
-  if (lane == 0) out_nres[q] = found;
+  if (threadIdx.x == 0) out_nres[q] = found;
 }
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
@@ -687,7 +773,8 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
   const uint64_t P_BUDGET = 1ull << 28;
   m_bits mb;
   mb.sb = bits_for(t->max_sid);
-  mb.dbits = bits_for((uint64_t)t->max_off + (1ull << QOFF_BITS));
+  mb.dbits = 0;
+  mb.bias = 0;
   // whole query set on the device once
   const uint64_t h0 = query_off[0], h1 = query_off[n_queries];
   const uint32_t *d_key = key32, *d_qo = q_off;
@@ -710,10 +797,6 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
     const uint64_t m = query_off[q0 + nq] - query_off[q0];
     if (m >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u has too many hashes", q0);
     mb.qb = bits_for(nq - 1);
-    if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
-      if (nq > 1) { step = nq / 2; continue; }
-      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
-    }
     void *d_qoff, *c0, *c1, *fl, *ps, *tot, *err;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
     SHZ_HIP(ctx, hipMemcpyAsync(d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -748,11 +831,17 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
                        (const uint32_t*)fl, (const uint32_t*)ps, m, E);
     SHZ_HIP(ctx, hipGetLastError());
     uint64_t mu = 0;
-    uint32_t herr = 0;
+    uint32_t herr[2] = {0, 0};
     SHZ_HIP(ctx, hipMemcpyAsync(&mu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(herr, err, 8, hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (herr) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
+    if (herr[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
+    mb.bias = herr[1];
+    mb.dbits = bits_for((uint64_t)t->max_off + mb.bias);
+    if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
+      if (nq > 1) { step = nq / 2; continue; }
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
+    }
     // groups = distinct (query, key)
     void *gs, *glo, *grows, *gpairs, *po;
     hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint64_t*)E, mu, QKEY_SHIFT,
@@ -829,16 +918,16 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
       const uint32_t nr = (uint32_t)nr64;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 4, &gh));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nr * 4, &gc));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
+      gc = nullptr;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
       hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl,
                          (const uint32_t*)rps, P, (const uint64_t*)tot + 4, (uint32_t*)rs);
       hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                         (uint32_t*)gh, (uint32_t*)gc, (uint32_t*)gd, (uint32_t*)gdd);
-      hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(64), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                         (const uint32_t*)gh, (const uint32_t*)gc, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
+                         (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
+      hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                         (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
                          (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
       SHZ_HIP(ctx, hipGetLastError());
     }
