@@ -150,6 +150,11 @@ int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, const uint32
                                uint32_t n_clips, uint32_t sid0, uint32_t flags);
 /* sort staged+existing rows by (key, sid, off), drop duplicates, build the bucket index */
 int32_t shz_table_finalize(shz_table* t);
+/* A table is a list of sorted segments (each one radix sort, < 2^32 rows) that every probe visits; rows
+ * beyond `rows` per segment open a new one at finalize.  Default 2^31; smaller values only for tests.
+ * Duplicates are removed inside a segment (the caller must not insert the same song twice across
+ * finalize calls that land in different segments). */
+int32_t shz_table_set_segment_rows(shz_table* t, uint64_t rows);
 int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged);
 /* sorted rows to host (dump / parity): arrays of cap rows */
 int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap, uint64_t* count);

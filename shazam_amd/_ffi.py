@@ -52,6 +52,7 @@ SIGNATURES = {
     "shz_table_insert": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, C.c_uint32]),
     "shz_table_insert_clips": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "shz_table_finalize": (C.c_int32, [vp]),
+    "shz_table_set_segment_rows": (C.c_int32, [vp, C.c_uint64]),
     "shz_table_rows": (C.c_int32, [vp, u64p, u64p]),
     "shz_table_export": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, u64p]),
     "shz_table_lookup": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]),
@@ -371,6 +372,9 @@ class Table:
             t1 = np.ascontiguousarray(t1, np.uint32)
         self.ctx.check(lib().shz_table_insert_clips(self.h, ptr(key32), ptr(t1), ho.ctypes.data_as(u64p), len(ho) - 1, sid0,
                                                     IN_DEVICE if device else 0))
+
+    def set_segment_rows(self, rows: int):
+        self.ctx.check(lib().shz_table_set_segment_rows(self.h, int(rows)))
 
     def finalize(self):
         self.ctx.check(lib().shz_table_finalize(self.h))

@@ -10,9 +10,25 @@
 
 #include "shz_internal.h"
 
+// A table is a list of immutable sorted SEGMENTS (each < 2^32 rows, its own bucket index) plus the
+// active segment below that new rows are merged into; a probe visits every segment.  Segments lift
+// the 2^32-row limit of one radix sort (BASELINE config 3: 7.1e9 rows = 85 GB fits one GPU's HBM).
+struct shz_seg {
+  uint32_t *key, *sid, *off, *bucket;
+  uint64_t n, nbuckets;
+};
+struct shz_seg_dev {  // what the match kernels see
+  const uint32_t *key, *sid, *off, *bucket;
+  uint32_t n;
+  uint64_t nbuckets;
+};
+#define SHZ_MAX_SEGS 32
+
 struct shz_table {
   shz_ctx* ctx = nullptr;
-  uint32_t *key = nullptr, *sid = nullptr, *off = nullptr;
+  std::vector<shz_seg> done;           // frozen segments
+  uint64_t seg_limit = 1ull << 31;     // rows per segment (bounds the sort scratch: 16 B/row)
+  uint32_t *key = nullptr, *sid = nullptr, *off = nullptr;   // active segment
   uint64_t n = 0;
   uint32_t *skey = nullptr, *ssid = nullptr, *soff = nullptr;
   uint64_t ns = 0, scap = 0;
@@ -20,6 +36,17 @@ struct shz_table {
   uint64_t nbuckets = 0;  // bucket has nbuckets+1 entries
   uint32_t max_sid = 0, max_off = 0;
 };
+
+static std::vector<shz_seg> all_segs(const shz_table* t) {
+  std::vector<shz_seg> v = t->done;
+  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
+  return v;
+}
+static uint64_t total_rows(const shz_table* t) {
+  uint64_t n = t->n;
+  for (const shz_seg& g : t->done) n += g.n;
+  return n;
+}
 
 static int bits_for(uint64_t v) {
   int b = 0;
@@ -159,6 +186,24 @@ __global__ void tbl_compact1_kernel(const uint64_t* __restrict__ c, const uint32
   ooff[p] = (uint32_t)(v & ((1ull << ob) - 1));
 }
 
+__device__ __forceinline__ uint32_t slice_of(uint32_t key, uint32_t nsl) { return ((key * 2654435761u) >> 12) % nsl; }
+__global__ void tbl_slice_flag_kernel(const uint32_t* __restrict__ key, uint64_t n, uint32_t nsl, uint32_t want,
+                                      uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = slice_of(key[i], nsl) == want ? 1u : 0u;
+}
+__global__ void tbl_slice_scatter_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
+                                         const uint32_t* __restrict__ off, const uint32_t* __restrict__ flag,
+                                         const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ ok,
+                                         uint32_t* __restrict__ os, uint32_t* __restrict__ oo) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t p = pos[i];
+  ok[p] = key[i];
+  os[p] = sid[i];
+  oo[p] = off[i];
+}
+
 // ---------------------------------------------------------------------------------------- table API
 extern "C" int32_t shz_table_create(shz_ctx* ctx, shz_table** out) {
   if (!ctx || !out) return SHZ_E_INVALID;
@@ -175,6 +220,11 @@ extern "C" int32_t shz_table_destroy(shz_table* t) {
   void* ps[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
   for (void* p : ps)
     if (p) (void)hipFree(p);
+  for (shz_seg& g : t->done) {
+    void* qs[] = {g.key, g.sid, g.off, g.bucket};
+    for (void* p : qs)
+      if (p) (void)hipFree(p);
+  }
   delete t;
   return SHZ_OK;
 }
@@ -253,20 +303,11 @@ extern "C" int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, c
   return SHZ_OK;
 }
 
-extern "C" int32_t shz_table_finalize(shz_table* t) {
-  if (!t) return SHZ_E_INVALID;
+// merge `ns` staged rows (columns skey/ssid/soff, not freed here) into the active segment
+static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_t* ssid, const uint32_t* soff, uint64_t ns) {
   shz_ctx* ctx = t->ctx;
-  SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  const uint64_t total = t->n + t->ns;
-  if (t->ns == 0 && (t->bucket || t->n == 0)) {
-    if (!t->bucket) {  // empty table: one empty bucket
-      SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
-      SHZ_HIP(ctx, hipMemsetAsync(t->bucket, 0, 8, ctx->stream));
-      t->nbuckets = 1;
-    }
-    return SHZ_OK;
-  }
-  if (total >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "table limited to < 2^32 rows (have %llu)", (unsigned long long)total);
+  const uint64_t total = t->n + ns;
+  if (total >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "segment limited to < 2^32 rows (have %llu)", (unsigned long long)total);
   void *k0, *k1, *v0 = nullptr, *v1 = nullptr, *mx, *fl, *ps, *tot;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &mx));
   SHZ_HIP(ctx, hipMemsetAsync(mx, 0, 64, ctx->stream));
@@ -274,15 +315,15 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   if (t->n)
     hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, gmax)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)t->sid, (const uint32_t*)t->off, t->n, (uint32_t*)mx);
-  if (t->ns)
-    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, gmax)), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, (uint32_t*)mx);
+  if (ns)
+    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((ns + 255) / 256, gmax)), dim3(256), 0, ctx->stream,
+                       ssid, soff, ns, (uint32_t*)mx);
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t maxes[2];
   SHZ_HIP(ctx, hipMemcpyAsync(maxes, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  t->max_sid = maxes[0];
-  t->max_off = maxes[1];
+  t->max_sid = std::max(t->max_sid, maxes[0]);   // table-wide maxima size the packed vote key
+  t->max_off = std::max(t->max_off, maxes[1]);
   const int sb = bits_for(maxes[0]), ob = bits_for(maxes[1]);
   const bool one_key = sb + ob <= 32;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, total * 8, &k0));
@@ -298,10 +339,9 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
       hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, 8192)), dim3(256), 0,
                          ctx->stream, (const uint32_t*)t->key, (const uint32_t*)t->sid, (const uint32_t*)t->off, t->n,
                          (uint64_t)0, sb, ob, ka);
-    if (t->ns)
-      hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 8192)), dim3(256), 0,
-                         ctx->stream, (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns,
-                         t->n, sb, ob, ka);
+    if (ns)
+      hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((ns + 255) / 256, 8192)), dim3(256), 0,
+                         ctx->stream, skey, ssid, soff, ns, t->n, sb, ob, ka);
     SHZ_HIP(ctx, hipGetLastError());
     SHZ_TRY(shz_sort_u64(ctx, ka, kb, nullptr, nullptr, 0, total, 0, 32 + sb + ob, &sel));
     if (sel) std::swap(ka, kb);
@@ -315,9 +355,9 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
     if (t->n)
       hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)std::min<uint64_t>((t->n + 255) / 256, 4096)), dim3(256), 0,
                          ctx->stream, t->key, t->sid, t->off, t->n, (uint64_t)0, ka, (uint32_t*)va, (uint32_t*)mx);
-    if (t->ns)
-      hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 4096)), dim3(256), 0,
-                         ctx->stream, t->skey, t->ssid, t->soff, t->ns, t->n, ka, (uint32_t*)va, (uint32_t*)mx);
+    if (ns)
+      hipLaunchKernelGGL(tbl_compose_kernel, dim3((unsigned)std::min<uint64_t>((ns + 255) / 256, 4096)), dim3(256), 0,
+                         ctx->stream, skey, ssid, soff, ns, t->n, ka, (uint32_t*)va, (uint32_t*)mx);
     SHZ_HIP(ctx, hipGetLastError());
     // 1) stable sort by (sid, off) carrying the key, 2) stable sort by key carrying (sid, off)
     SHZ_TRY(shz_sort_u64(ctx, ka, kb, va, vb, 4, total, 0, ob, &sel));
@@ -341,11 +381,11 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // the old columns are dead once composed: free them before allocating the new ones (peak memory)
   {
-    void* olds[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
+    void* olds[] = {t->key, t->sid, t->off, t->bucket};
     for (void* p : olds)
       if (p) SHZ_HIP(ctx, hipFree(p));
-    t->key = t->sid = t->off = t->skey = t->ssid = t->soff = t->bucket = nullptr;
-    t->n = t->ns = t->scap = 0;
+    t->key = t->sid = t->off = t->bucket = nullptr;
+    t->n = 0;
   }
   uint32_t *nk, *nsid, *noff;
   if (hipMalloc(&nk, nu * 4 + 4) != hipSuccess || hipMalloc(&nsid, nu * 4 + 4) != hipSuccess ||
@@ -363,8 +403,6 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   SHZ_HIP(ctx, hipMemcpyAsync(&last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->key = nk; t->sid = nsid; t->off = noff;
-  t->skey = t->ssid = t->soff = nullptr;
-  t->ns = t->scap = 0;
   t->n = nu;
   t->nbuckets = (uint64_t)(last_key >> 8) + 1;
   t->bucket = nullptr;
@@ -376,9 +414,81 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   return SHZ_OK;
 }
 
+
+static void freeze_active(shz_table* t) {
+  if (!t->n) return;
+  t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
+  t->key = t->sid = t->off = t->bucket = nullptr;
+  t->n = t->nbuckets = 0;
+}
+
+extern "C" int32_t shz_table_finalize(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->ns == 0) {
+    if (!t->bucket && t->n == 0 && t->done.empty()) {  // empty table: one empty bucket
+      SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
+      SHZ_HIP(ctx, hipMemsetAsync(t->bucket, 0, 8, ctx->stream));
+      t->nbuckets = 1;
+    }
+    return SHZ_OK;
+  }
+  // staged rows go into the active segment if they fit; otherwise the active segment is frozen and the
+  // staged rows are cut into slices BY KEY (all copies of a row land in the same slice, so duplicates
+  // inside one batch are still removed), one new segment per slice
+  if (t->n + t->ns <= t->seg_limit) {
+    SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns));
+  } else {
+    freeze_active(t);
+    const uint32_t nsl = (uint32_t)((t->ns + t->seg_limit - 1) / t->seg_limit) + (t->ns > t->seg_limit ? 1 : 0);
+    if (t->done.size() + nsl > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
+    for (uint32_t sl = 0; sl < nsl; ++sl) {
+      if (nsl == 1) {
+        SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns));
+      } else {
+        void *fl, *ps, *tot, *ck, *cs, *co;
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, t->ns * 4, &fl));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, t->ns * 4, &ps));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
+        hipLaunchKernelGGL(tbl_slice_flag_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)t->skey, t->ns, nsl, sl, (uint32_t*)fl);
+        SHZ_HIP(ctx, hipGetLastError());
+        SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, t->ns, (uint64_t*)tot));
+        uint64_t cnt = 0;
+        SHZ_HIP(ctx, hipMemcpyAsync(&cnt, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (cnt == 0) continue;
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, cnt * 4, &ck));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, cnt * 4, &cs));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, cnt * 4, &co));
+        hipLaunchKernelGGL(tbl_slice_scatter_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff,
+                           (const uint32_t*)fl, (const uint32_t*)ps, t->ns, (uint32_t*)ck, (uint32_t*)cs, (uint32_t*)co);
+        SHZ_HIP(ctx, hipGetLastError());
+        SHZ_TRY(finalize_active(t, (const uint32_t*)ck, (const uint32_t*)cs, (const uint32_t*)co, cnt));
+      }
+      if (sl + 1 < nsl) freeze_active(t);
+    }
+  }
+  void* st[] = {t->skey, t->ssid, t->soff};
+  for (void* p : st)
+    if (p) SHZ_HIP(ctx, hipFree(p));
+  t->skey = t->ssid = t->soff = nullptr;
+  t->ns = t->scap = 0;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_set_segment_rows(shz_table* t, uint64_t rows) {
+  if (!t) return SHZ_E_INVALID;
+  if (rows < 16 || rows >= (1ull << 32)) SHZ_FAIL(t->ctx, SHZ_E_INVALID, "segment rows must be in [16, 2^32)");
+  t->seg_limit = rows;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged) {
   if (!t) return SHZ_E_INVALID;
-  if (n_rows) *n_rows = t->n;
+  if (n_rows) *n_rows = total_rows(t);
   if (n_staged) *n_staged = t->ns;
   return SHZ_OK;
 }
@@ -387,14 +497,19 @@ extern "C" int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid
                                     uint64_t* count) {
   if (!t) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
-  if (count) *count = t->n;
+  const uint64_t nrows = total_rows(t);
+  if (count) *count = nrows;
   if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has %llu staged rows; call shz_table_finalize first", (unsigned long long)t->ns);
-  if (t->n > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)t->n);
-  if (t->n == 0) return SHZ_OK;
+  if (nrows > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)nrows);
+  if (nrows == 0) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  SHZ_HIP(ctx, hipMemcpyAsync(key32, t->key, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sid, t->sid, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(off, t->off, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint64_t pos = 0;
+  for (const shz_seg& g : all_segs(t)) {  // segment after segment; rows are sorted inside a segment
+    SHZ_HIP(ctx, hipMemcpyAsync(key32 + pos, g.key, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(sid + pos, g.sid, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(off + pos, g.off, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    pos += g.n;
+  }
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -404,13 +519,14 @@ extern "C" int32_t shz_table_song_rows(shz_table* t, uint32_t sid, uint64_t* n_r
   shz_ctx* ctx = t->ctx;
   if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has staged rows; call shz_table_finalize first");
   *n_rows = 0;
-  if (t->n == 0) return SHZ_OK;
+  if (total_rows(t) == 0) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void* d;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &d));
   SHZ_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(tbl_count_sid_kernel, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)t->sid, t->n, sid, (unsigned long long*)d);
+  for (const shz_seg& g : all_segs(t))
+    hipLaunchKernelGGL(tbl_count_sid_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)g.sid, g.n, sid, (unsigned long long*)d);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_HIP(ctx, hipMemcpyAsync(n_rows, d, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -454,15 +570,11 @@ __global__ void tbl_lookup_gather_kernel(const uint32_t* __restrict__ lo, const 
   ooff[p] = toff[row];
 }
 
-extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t n_keys, uint32_t* key32, uint32_t* sid,
-                                    uint32_t* off, uint64_t cap, uint64_t* count) {
-  if (!t) return SHZ_E_INVALID;
+// rows of the listed keys inside ONE segment: device gather, host arrays + per-key prefix (n_keys+1)
+static int32_t lookup_segment(shz_table* t, const shz_seg& g, const uint32_t* keys, uint64_t n_keys,
+                              std::vector<uint32_t>& ok_, std::vector<uint32_t>& os_, std::vector<uint32_t>& oo_,
+                              std::vector<uint64_t>& po_) {
   shz_ctx* ctx = t->ctx;
-  if (count) *count = 0;
-  if (t->ns || !t->bucket) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
-  if (n_keys == 0) return SHZ_OK;
-  if (!keys) SHZ_FAIL(ctx, SHZ_E_INVALID, "keys is NULL");
-  SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void *dk, *dlo, *dcnt, *dpo, *tot;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, n_keys * 4, &dk));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n_keys * 4, &dlo));
@@ -471,29 +583,61 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &tot));
   SHZ_HIP(ctx, hipMemcpyAsync(dk, keys, n_keys * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(tbl_lookup_count_kernel, dim3((unsigned)((n_keys + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)dk, n_keys, (const uint32_t*)t->key, (uint32_t)t->n, (const uint32_t*)t->bucket,
-                     t->nbuckets, (uint32_t*)dlo, (uint64_t*)dcnt);
+                     (const uint32_t*)dk, n_keys, (const uint32_t*)g.key, (uint32_t)g.n, (const uint32_t*)g.bucket,
+                     g.nbuckets, (uint32_t*)dlo, (uint64_t*)dcnt);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)dcnt, (uint64_t*)dpo, n_keys + 1, (uint64_t*)tot));
-  uint64_t total = 0;
-  SHZ_HIP(ctx, hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  po_.resize(n_keys + 1);
+  SHZ_HIP(ctx, hipMemcpyAsync(po_.data(), dpo, (n_keys + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (count) *count = total;
-  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)total);
+  const uint64_t total = po_[n_keys];
+  ok_.resize(total); os_.resize(total); oo_.resize(total);
   if (total == 0) return SHZ_OK;
-  if (!key32 || !sid || !off) SHZ_FAIL(ctx, SHZ_E_INVALID, "NULL output column");
   void *ok, *os, *oo;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, total * 4, &ok));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, total * 4, &os));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, total * 4, &oo));
   hipLaunchKernelGGL(tbl_lookup_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)dlo, (const uint64_t*)dpo, n_keys, total, (const uint32_t*)t->key,
-                     (const uint32_t*)t->sid, (const uint32_t*)t->off, (uint32_t*)ok, (uint32_t*)os, (uint32_t*)oo);
+                     (const uint32_t*)dlo, (const uint64_t*)dpo, n_keys, total, (const uint32_t*)g.key,
+                     (const uint32_t*)g.sid, (const uint32_t*)g.off, (uint32_t*)ok, (uint32_t*)os, (uint32_t*)oo);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_HIP(ctx, hipMemcpyAsync(key32, ok, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sid, os, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(off, oo, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(ok_.data(), ok, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(os_.data(), os, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(oo_.data(), oo, total * 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t n_keys, uint32_t* key32, uint32_t* sid,
+                                    uint32_t* off, uint64_t cap, uint64_t* count) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (count) *count = 0;
+  if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (n_keys == 0) return SHZ_OK;
+  if (!keys) SHZ_FAIL(ctx, SHZ_E_INVALID, "keys is NULL");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const std::vector<shz_seg> segs = all_segs(t);
+  std::vector<std::vector<uint32_t>> K(segs.size()), S(segs.size()), O(segs.size());
+  std::vector<std::vector<uint64_t>> PO(segs.size());
+  uint64_t total = 0;
+  for (size_t i = 0; i < segs.size(); ++i) {
+    SHZ_TRY(lookup_segment(t, segs[i], keys, n_keys, K[i], S[i], O[i], PO[i]));
+    total += K[i].size();
+  }
+  if (count) *count = total;
+  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)total);
+  if (total == 0) return SHZ_OK;
+  if (!key32 || !sid || !off) SHZ_FAIL(ctx, SHZ_E_INVALID, "NULL output column");
+  uint64_t pos = 0;  // grouped in key-list order; inside a key: segment order, then (song_id, offset)
+  for (uint64_t k = 0; k < n_keys; ++k)
+    for (size_t i = 0; i < segs.size(); ++i)
+      for (uint64_t r = PO[i][k]; r < PO[i][k + 1]; ++r) {
+        key32[pos] = K[i][r];
+        sid[pos] = S[i][r];
+        off[pos] = O[i][r];
+        ++pos;
+      }
   return SHZ_OK;
 }
 
@@ -582,39 +726,44 @@ __global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const ui
   if (i < n && flag[i]) starts[pos[i]] = (uint32_t)i;
 }
 
+// probe: rows [lo, lo+rows) of every (query, key) group in every segment; g_lo / g_rows are [nseg][ng+1]
 __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
-                               const uint32_t* __restrict__ tkey, uint32_t tn, const uint32_t* __restrict__ bucket,
-                               uint64_t nbuckets, uint32_t* __restrict__ g_lo, uint32_t* __restrict__ g_rows,
-                               uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total) {
+                               const shz_seg_dev* __restrict__ segs, int nseg, uint32_t* __restrict__ g_lo,
+                               uint32_t* __restrict__ g_rows, uint64_t* __restrict__ g_pairs,
+                               unsigned long long* __restrict__ rows_total) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t rows = 0;
+  unsigned long long rows_all = 0;
   if (g < ng) {
     const uint32_t e0 = gs[g];
     const uint32_t key = (uint32_t)(E[e0] >> QKEY_SHIFT);
     const uint64_t b = key >> 8;
-    uint32_t lo = 0;
-    if (b < nbuckets && tn) {
-      uint32_t l = bucket[b], h = bucket[b + 1];
-      const uint32_t h0 = h;
-      while (l < h) {  // lower_bound(key)
-        uint32_t mid = l + ((h - l) >> 1);
-        if (tkey[mid] < key) l = mid + 1; else h = mid;
+    for (int sg = 0; sg < nseg; ++sg) {
+      const uint32_t* __restrict__ tkey = segs[sg].key;
+      uint32_t lo = 0, rows = 0;
+      if (b < segs[sg].nbuckets && segs[sg].n) {
+        uint32_t l = segs[sg].bucket[b], h = segs[sg].bucket[b + 1];
+        const uint32_t h0 = h;
+        while (l < h) {  // lower_bound(key)
+          uint32_t mid = l + ((h - l) >> 1);
+          if (tkey[mid] < key) l = mid + 1; else h = mid;
+        }
+        lo = l;
+        h = h0;
+        while (l < h) {  // upper_bound(key)
+          uint32_t mid = l + ((h - l) >> 1);
+          if (tkey[mid] <= key) l = mid + 1; else h = mid;
+        }
+        rows = l - lo;
       }
-      lo = l;
-      h = h0;
-      while (l < h) {  // upper_bound(key)
-        uint32_t mid = l + ((h - l) >> 1);
-        if (tkey[mid] <= key) l = mid + 1; else h = mid;
-      }
-      rows = l - lo;
+      g_lo[(uint64_t)sg * (ng + 1) + g] = lo;
+      g_rows[(uint64_t)sg * (ng + 1) + g] = rows;
+      rows_all += rows;
     }
-    g_lo[g] = lo;
-    g_rows[g] = rows;
-    g_pairs[g] = (uint64_t)rows * (gs[g + 1] - e0);
+    g_pairs[g] = rows_all * (gs[g + 1] - e0);
   } else if (g == ng) {
     g_pairs[g] = 0;  // sentinel so the exclusive scan yields po[ng] = total
   }
-  unsigned long long s = rows;
+  unsigned long long s = rows_all;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor((long long)s, d, 64);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total, s);
@@ -645,8 +794,8 @@ struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset
 
 __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
                                 const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
-                                const uint32_t* __restrict__ tsid, const uint32_t* __restrict__ toff, uint64_t P,
-                                m_bits mb, uint64_t* __restrict__ v) {
+                                const uint32_t* __restrict__ g_rows, const shz_seg_dev* __restrict__ segs, int nseg,
+                                uint64_t P, m_bits mb, uint64_t* __restrict__ v) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   uint32_t l = 0, h = ng;  // last g with po[g] <= p
@@ -657,7 +806,17 @@ __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* 
   const uint32_t g = l;
   const uint32_t e0 = gs[g], noff = gs[g + 1] - e0;
   const uint64_t r = p - po[g];
-  const uint32_t row = g_lo[g] + (uint32_t)(r / noff), oi = (uint32_t)(r % noff);
+  uint64_t ridx = r / noff;  // row number inside the group's rows, segment after segment
+  const uint32_t oi = (uint32_t)(r % noff);
+  int sg = 0;
+  for (; sg < nseg - 1; ++sg) {
+    const uint32_t rs_ = g_rows[(uint64_t)sg * (ng + 1) + g];
+    if (ridx < rs_) break;
+    ridx -= rs_;
+  }
+  const uint32_t row = g_lo[(uint64_t)sg * (ng + 1) + g] + (uint32_t)ridx;
+  const uint32_t* __restrict__ tsid = segs[sg].sid;
+  const uint32_t* __restrict__ toff = segs[sg].off;
   const uint64_t e = E[e0 + oi];
   const uint64_t q = e >> QIDX_SHIFT;
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
@@ -763,7 +922,7 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
                                    uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs) {
   if (!ctx || !t) return SHZ_E_INVALID;
   if (t->ctx != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "table belongs to another ctx");
-  if (t->ns || !t->bucket) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
   if (n_queries == 0) return SHZ_OK;
   if (!query_off || !out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres)
     SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_batch: NULL buffer");
@@ -771,6 +930,14 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   ctx->st_rows = ctx->st_pairs = ctx->st_keys = 0;
   const uint64_t P_BUDGET = 1ull << 28;
+  // segment descriptors for the kernels (an empty table probes one empty segment)
+  std::vector<shz_seg_dev> hsegs;
+  for (const shz_seg& g : all_segs(t)) hsegs.push_back(shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets});
+  if (hsegs.empty()) hsegs.push_back(shz_seg_dev{nullptr, nullptr, nullptr, t->bucket, 0u, 0ull});
+  const int nseg = (int)hsegs.size();
+  void* d_segs;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, sizeof(shz_seg_dev) * SHZ_MAX_SEGS, &d_segs));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_segs, hsegs.data(), sizeof(shz_seg_dev) * nseg, hipMemcpyHostToDevice, ctx->stream));
   m_bits mb;
   mb.sb = bits_for(t->max_sid);
   mb.dbits = 0;
@@ -852,15 +1019,15 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t ng = (uint32_t)ng64;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)(ng + 1) * 4, &gs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)(ng + 1) * 4, &glo));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)(ng + 1) * 4, &grows));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)(ng + 1) * 4 * nseg, &glo));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)(ng + 1) * 4 * nseg, &grows));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)(ng + 1) * 8, &gpairs));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, (uint64_t)(ng + 1) * 8, &po));
     hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
                        (const uint32_t*)ps, mu, (const uint64_t*)tot + 1, (uint32_t*)gs);
     hipLaunchKernelGGL(m_probe_kernel, dim3(nblk((uint64_t)ng + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
-                       (const uint32_t*)gs, ng, (const uint32_t*)t->key, (uint32_t)t->n, (const uint32_t*)t->bucket,
-                       t->nbuckets, (uint32_t*)glo, (uint32_t*)grows, (uint64_t*)gpairs, (unsigned long long*)tot + 2);
+                       (const uint32_t*)gs, ng, (const shz_seg_dev*)d_segs, nseg, (uint32_t*)glo, (uint32_t*)grows,
+                       (uint64_t*)gpairs, (unsigned long long*)tot + 2);
     SHZ_HIP(ctx, hipGetLastError());
     SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, (uint64_t)ng + 1, (uint64_t*)tot + 3));
     uint64_t P = 0, rows_total = 0;
@@ -903,8 +1070,8 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
       hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                         ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)t->sid, (const uint32_t*)t->off, P,
-                         mb, (uint64_t*)v0);
+                         ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)grows, (const shz_seg_dev*)d_segs,
+                         nseg, P, mb, (uint64_t*)v0);
       SHZ_HIP(ctx, hipGetLastError());
       SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)v0, (uint64_t*)v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
       const uint64_t* vs = sel ? (const uint64_t*)v1 : (const uint64_t*)v0;
