@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--tone-amp", type=int, default=4000)
     ap.add_argument("--noise-amp", type=int, default=1500)
     ap.add_argument("--topn", type=int, default=2)
+    ap.add_argument("--finalize-every", type=int, default=0, help="songs between intermediate finalize calls (0 = once at the end)")
     a = ap.parse_args()
 
     from shazam_amd import _ffi, Table
@@ -47,7 +48,7 @@ def main():
     cap = a.chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
     pcm = ctx.alloc(a.chunk * n_samples * 2)
-    t_fp = t_ins = 0.0
+    t_fp = t_ins = t_fin = 0.0
     n_rows_in = 0
     t_build0 = time.perf_counter()
     for c0 in range(0, a.songs, a.chunk):
@@ -63,10 +64,15 @@ def main():
         tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
         t_ins += time.perf_counter() - t0
         n_rows_in += cnt
+        if a.finalize_every and (c0 + nc) % a.finalize_every == 0 and c0 + nc < a.songs:
+            t0 = time.perf_counter()
+            tbl.finalize()        # bounds staged rows + sort scratch; a full active segment is frozen
+            ctx.sync()
+            t_fin += time.perf_counter() - t0
     t0 = time.perf_counter()
     tbl.finalize()
     ctx.sync()
-    t_fin = time.perf_counter() - t0
+    t_fin += time.perf_counter() - t0
     t_build = time.perf_counter() - t_build0
     rows, _ = tbl.rows()
     pcm.free()
