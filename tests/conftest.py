@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """libshz.so is git-ignored (history stays source-only): build it in-tree when a fresh checkout runs
+    the tests before __graft_entry__.build() did (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = os.path.join(ROOT, "shazam_amd", "libshz.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shazam_amd", "csrc"), "-j4"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return lib
