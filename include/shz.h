@@ -67,6 +67,8 @@ int32_t shz_sync(shz_ctx* ctx);
 /* cap on the internal scratch arena (dB spectrogram, masks, sort buffers); batches are
  * split into sub-batches that fit.  0 = default (1/4 of HBM). */
 int32_t shz_set_workspace_limit(shz_ctx* ctx, uint64_t bytes);
+/* free the scratch arena (it regrows on demand); *freed_bytes may be NULL */
+int32_t shz_release_workspace(shz_ctx* ctx, uint64_t* freed_bytes);
 /* hipEvent timers on the ctx stream (replaces the time() deltas at recognizer.py:214-220,
  * 282-284, 388-390).  slot in [0,16). */
 int32_t shz_timer_start(shz_ctx* ctx, int32_t slot);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "shz_copy_d2h": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "shz_sync": (C.c_int32, [vp]),
     "shz_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
+    "shz_release_workspace": (C.c_int32, [vp, u64p]),
     "shz_timer_start": (C.c_int32, [vp, C.c_int32]),
     "shz_timer_stop": (C.c_int32, [vp, C.c_int32, C.POINTER(C.c_float)]),
     "shz_set_profiling": (C.c_int32, [vp, C.c_int32]),
@@ -178,6 +179,11 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         self.check(lib().shz_set_workspace_limit(self.h, int(nbytes)))
+
+    def release_workspace(self) -> int:
+        n = C.c_uint64()
+        self.check(lib().shz_release_workspace(self.h, C.byref(n)))
+        return n.value
 
     def timer_start(self, slot=0):
         self.check(lib().shz_timer_start(self.h, slot))

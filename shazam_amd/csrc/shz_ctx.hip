@@ -158,6 +158,22 @@ extern "C" int32_t shz_set_workspace_limit(shz_ctx* ctx, uint64_t bytes) {
   return SHZ_OK;
 }
 
+extern "C" int32_t shz_release_workspace(shz_ctx* ctx, uint64_t* freed_bytes) {
+  if (!ctx) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t freed = 0;
+  for (auto& b : ctx->ws)
+    if (b.p) {
+      SHZ_HIP(ctx, hipFree(b.p));
+      freed += b.cap;
+      b.p = nullptr;
+      b.cap = 0;
+    }
+  if (freed_bytes) *freed_bytes = freed;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_timer_start(shz_ctx* ctx, int32_t slot) {
   if (!ctx || slot < 0 || slot >= 16) return SHZ_E_INVALID;
   if (!ctx->tev_init) {
