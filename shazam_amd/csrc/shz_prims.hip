@@ -173,6 +173,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
 template <int VB> struct val_t { typedef uint32_t type; };
 template <> struct val_t<8> { typedef uint64_t type; };
 
+// Scatter of one pass.  The tile (4096 keys) is first re-ordered by digit inside LDS (stable: rounds in
+// memory order, ballot ranks inside a wave, wave prefixes across waves), then written out so that each
+// digit's run is one contiguous, coalesced global segment instead of 4096 scattered 8-byte stores.
 template <int VB>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys,
                                                                      const void* __restrict__ vals_,
@@ -183,21 +186,36 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   typedef typename val_t<VB>::type V;
   const V* vals = (const V*)vals_;
   V* ovals = (V*)ovals_;
-  __shared__ uint32_t running[256];      // global write cursor per digit for this block
+  __shared__ uint64_t skey[SORT_TILE];
+  __shared__ V sval[VB ? SORT_TILE : 1];
+  __shared__ uint32_t lstart[256];       // first LDS slot of each digit's run
+  __shared__ uint32_t gbase[256];        // first global slot of each digit's run of this tile
+  __shared__ uint32_t running[256];      // LDS write cursor per digit
   __shared__ uint32_t cnt[4][256];       // per-wave digit counts of the current round
+  __shared__ uint32_t scan_tmp[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  running[threadIdx.x] = offs[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
   const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+  const uint32_t tile_n = (uint32_t)(n - base < SORT_TILE ? n - base : SORT_TILE);
+  {  // digit counts of this tile from the scanned histogram: next flattened entry minus this one
+    const uint64_t f = (uint64_t)threadIdx.x * nblocks + blockIdx.x;
+    const uint32_t g0 = offs[f];
+    const uint32_t g1 = (f + 1 < (uint64_t)256 * nblocks) ? offs[f + 1] : (uint32_t)n;
+    uint32_t tot;
+    const uint32_t ls = block_excl_scan<uint32_t>(g1 - g0, &tot, scan_tmp);
+    gbase[threadIdx.x] = g0;
+    lstart[threadIdx.x] = ls;
+    running[threadIdx.x] = ls;
+  }
   for (int r = 0; r < SORT_ROUNDS; ++r) {
-    const uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
-    if (base + (uint64_t)r * SORT_THREADS >= n) break;  // uniform
+    const uint32_t li = (uint32_t)r * SORT_THREADS + threadIdx.x;
+    if ((uint32_t)r * SORT_THREADS >= tile_n) break;  // uniform
 #pragma unroll
     for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
-    const bool valid = i < n;
-    uint64_t k = valid ? keys[i] : 0;
+    const bool valid = li < tile_n;
+    uint64_t k = valid ? keys[base + li] : 0;
     V v = 0;
-    if (VB != 0 && valid) v = vals[i];
+    if (VB != 0 && valid) v = vals[base + li];
     const uint32_t d = (uint32_t)(k >> shift) & 255u;
     // lanes of this wave holding the same digit (invalid lanes form their own class)
     unsigned long long peers = __ballot(valid);
@@ -219,10 +237,17 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
     __syncthreads();
     running[threadIdx.x] += cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
     if (valid) {
-      okeys[pos] = k;
-      if (VB != 0) ovals[pos] = v;
+      skey[pos] = k;
+      if (VB != 0) sval[pos] = v;
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
+    const uint64_t k = skey[i];
+    const uint32_t d = (uint32_t)(k >> shift) & 255u;
+    const uint32_t g = gbase[d] + (i - lstart[d]);
+    okeys[g] = k;
+    if (VB != 0) ovals[g] = sval[i];
   }
 }
 
