@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshz.so")
+LIB_PATH = os.environ.get("SHZ_LIB") or os.path.join(_HERE, "libshz.so")  # SHZ_LIB: A/B builds of the same ABI
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 PCM_DEVICE, OUT_DEVICE, IN_DEVICE = 1, 2, 4
