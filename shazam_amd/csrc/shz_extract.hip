@@ -261,6 +261,44 @@ struct peak_seg {
 // line: it runs only for local maxima whose power lies within 1e-9 of the threshold
 __device__ __noinline__ bool db_above(double p, double amp_min) { return 10.0 * log10(p) > amp_min; }
 
+// --- LDS reads of peak_pick as explicit single ds_read_b64 (see the comment at their use) ---
+typedef __attribute__((address_space(3))) const double pk_lds_cd;
+template <int OFF>
+__device__ __forceinline__ double pk_lds_ld(uint32_t a) {
+  double x;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x) : "v"(a), "n"(OFF) : "memory");
+  return x;
+}
+// row ROW of the group: x[0..9] = pr2[ROW][j + 2d], x[10] = raw[ROW][j + 20]   (rows are 256 doubles apart)
+template <int ROW>
+__device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, uint32_t a_raw, double (&x)[11]) {
+  x[0] = pk_lds_ld<ROW * 2048 + 0>(a_pr2);
+  x[1] = pk_lds_ld<ROW * 2048 + 16>(a_pr2);
+  x[2] = pk_lds_ld<ROW * 2048 + 32>(a_pr2);
+  x[3] = pk_lds_ld<ROW * 2048 + 48>(a_pr2);
+  x[4] = pk_lds_ld<ROW * 2048 + 64>(a_pr2);
+  x[5] = pk_lds_ld<ROW * 2048 + 80>(a_pr2);
+  x[6] = pk_lds_ld<ROW * 2048 + 96>(a_pr2);
+  x[7] = pk_lds_ld<ROW * 2048 + 112>(a_pr2);
+  x[8] = pk_lds_ld<ROW * 2048 + 128>(a_pr2);
+  x[9] = pk_lds_ld<ROW * 2048 + 144>(a_pr2);
+  x[10] = pk_lds_ld<ROW * 2048>(a_raw);
+}
+// wait until at most N of this wave's LDS operations are outstanding; the operands tie the values to the wait so
+// that no use of them is scheduled above it
+#define PK_WAIT(x, N)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                         \
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),    \
+                 "+v"(x[8]), "+v"(x[9]), "+v"(x[10])                                                                \
+               :                                                                                                   \
+               : "memory")
+__device__ __forceinline__ double pk_row_max(const double (&x)[11]) {
+  const double a = fmax(fmax(x[0], x[1]), fmax(x[2], x[3]));
+  const double b = fmax(fmax(x[4], x[5]), fmax(x[6], x[7]));
+  const double c = fmax(fmax(x[8], x[9]), x[10]);
+  return fmax(fmax(a, b), c);
+}
+
 template <bool POWER>
 __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restrict__ A, uint32_t row_stride,
                                                         uint32_t n_bins, const peak_seg* __restrict__ segs,
@@ -284,6 +322,8 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   const int hi = (int)(sg.t1 + 10 < sg.nframes ? sg.t1 + 10 : sg.nframes);
   const int end = (int)sg.t1 + 10;  // last iteration decides frame t1-1
   const double* src = A + (uint64_t)sg.gframe0 * row_stride + (loads ? col : 0);
+  const uint32_t a_pr2 = (uint32_t)(uintptr_t)(pk_lds_cd*)&pr2[0][j < PK_SW ? j : 0];
+  const uint32_t a_raw = (uint32_t)(uintptr_t)(pk_lds_cd*)&raw[0][j < PK_SW ? j + 20 : 0];
 
   double prevS[21], cur[21], pre[PK_PF];
   uint32_t fc = 0, fp = 0, sp = 0;  // row-max flags of the current / previous block, suffix-max flags
@@ -318,15 +358,22 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
         for (int i = 0; i < PK_PF; ++i) pr2[i][li] = fmax(v[i], (li + 1 < PK_COLS) ? raw[i][li + 1] : NEG);
       }
       __syncthreads();
+      // Row maxima over columns j .. j+20 = pairs (j, j+1) .. (j+18, j+19) and column j+20.  The eleven reads of a
+      // row are single ds_read_b64 (2 LDS-array cycles each); left to the compiler they are fused in pairs into
+      // ds_read2_b64 at 8 cycles per pair (PMC: 2,201 -> 1,403 LDS-array cycles per frame).  Two rows are in
+      // flight: the reads of row i+1 are issued before row i is reduced.
 #pragma unroll
-      for (int i = 0; i < PK_PF; ++i) {
-        double m = NEG;
-        if (j < PK_SW) {  // window columns j .. j+20 of the row = pairs (j, j+1) .. (j+18, j+19) and j+20
-          m = raw[i][j + 20];
-#pragma unroll
-          for (int d = 0; d < 10; ++d) m = fmax(m, pr2[i][j + 2 * d]);
-        }
-        m1[i] = m;
+      for (int i = 0; i < PK_PF; ++i) m1[i] = NEG;
+      if (j < PK_SW) {
+        double xa[11], xb[11];
+        pk_row_reads<0>(a_pr2, a_raw, xa);
+        pk_row_reads<1>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[0] = pk_row_max(xa);
+        pk_row_reads<2>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[1] = pk_row_max(xb);
+        pk_row_reads<3>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[2] = pk_row_max(xa);
+        pk_row_reads<4>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[3] = pk_row_max(xb);
+        pk_row_reads<5>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[4] = pk_row_max(xa);
+        pk_row_reads<6>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[5] = pk_row_max(xb);
+        PK_WAIT(xa, 0); m1[6] = pk_row_max(xa);
       }
       // time direction (registers only)
 #pragma unroll
