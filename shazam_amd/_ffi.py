@@ -66,6 +66,14 @@ SIGNATURES = {
     "shz_comm_destroy": (C.c_int32, [vp]),
     "shz_table_allgather": (C.c_int32, [vp, vp, u64p]),
     "shz_comm_barrier": (C.c_int32, [vp]),
+    "shz_shard_of_keys": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp]),
+    "shz_table_keep_shard": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
+    "shz_table_shard_exchange": (C.c_int32, [vp, vp, u64p]),
+    "shz_match_votes": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, u64p,
+                                    vp, vp]),
+    "shz_votes_allgather": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, u64p]),
+    "shz_votes_merge": (C.c_int32, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    vp, vp, vp, vp, vp]),
 }
 
 

@@ -18,6 +18,8 @@ struct rccl_api {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -39,6 +41,8 @@ static rccl_api* rccl() {
       *(void**)&api.CommDestroy = dlsym(api.lib, "ncclCommDestroy");
       *(void**)&api.AllGather = dlsym(api.lib, "ncclAllGather");
       *(void**)&api.Broadcast = dlsym(api.lib, "ncclBroadcast");
+      *(void**)&api.Send = dlsym(api.lib, "ncclSend");
+      *(void**)&api.Recv = dlsym(api.lib, "ncclRecv");
       *(void**)&api.GroupStart = dlsym(api.lib, "ncclGroupStart");
       *(void**)&api.GroupEnd = dlsym(api.lib, "ncclGroupEnd");
       *(void**)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
@@ -97,6 +101,7 @@ extern "C" int32_t shz_comm_destroy(shz_comm* c) {
 }
 
 // internal: used by shz_table_allgather (shz_table.hip)
+shz_ctx* shz_comm_ctx(shz_comm* c) { return c->ctx; }
 int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks) {
   *rank = c->rank;
   *nranks = c->nranks;
@@ -123,6 +128,30 @@ int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv,
     SHZ_NCCL(ctx, r->Broadcast(src, (char*)d_recv + displ[p], counts[p], NCCL_U8, p, c->comm, ctx->stream));
   }
   if (r->GroupEnd) SHZ_NCCL(ctx, r->GroupEnd());
+  return SHZ_OK;
+}
+
+// all-to-all of variable-size byte blocks as one group of point-to-point transfers: the block for rank p
+// starts at d_send + sdispl[p] (scount[p] bytes); the block from rank p lands at d_recv + rdispl[p].
+// Every pair of GPUs exchanges directly over its own xGMI link; the block a rank keeps for itself is a
+// device-to-device copy.
+int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t* scount, const uint64_t* sdispl,
+                                 void* d_recv, const uint64_t* rcount, const uint64_t* rdispl) {
+  shz_ctx* ctx = c->ctx;
+  rccl_api* r = rccl();
+  if (scount[c->rank] != rcount[c->rank]) SHZ_FAIL(ctx, SHZ_E_INVALID, "alltoallv: self block sizes differ");
+  if (scount[c->rank])
+    SHZ_HIP(ctx, hipMemcpyAsync((char*)d_recv + rdispl[c->rank], (const char*)d_send + sdispl[c->rank], scount[c->rank],
+                                hipMemcpyDeviceToDevice, ctx->stream));
+  if (c->nranks == 1) return SHZ_OK;
+  if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclSend/ncclRecv");
+  SHZ_NCCL(ctx, r->GroupStart());
+  for (int p = 0; p < c->nranks; ++p) {
+    if (p == c->rank) continue;
+    if (scount[p]) SHZ_NCCL(ctx, r->Send((const char*)d_send + sdispl[p], scount[p], NCCL_U8, p, c->comm, ctx->stream));
+    if (rcount[p]) SHZ_NCCL(ctx, r->Recv((char*)d_recv + rdispl[p], rcount[p], NCCL_U8, p, c->comm, ctx->stream));
+  }
+  SHZ_NCCL(ctx, r->GroupEnd());
   return SHZ_OK;
 }
 

@@ -118,6 +118,9 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
 
 // ---- RCCL helpers (shz_comm.hip) ----------------------------------------------------------
 int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks);
+shz_ctx* shz_comm_ctx(shz_comm* c);
 int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes);
+int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t* scount, const uint64_t* sdispl,
+                                 void* d_recv, const uint64_t* rcount, const uint64_t* rdispl);
 int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
                                   const uint64_t* displ);

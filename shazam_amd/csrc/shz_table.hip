@@ -916,17 +916,43 @@ __global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict_
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
-                                   const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
-                                   uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
-                                   uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs) {
+// one record per run of equal (query, sid, delta, first-offset flag) votes: the unit a key-sharded table hands over
+__global__ void m_runs_export_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs, uint32_t nr, m_bits mb,
+                                     uint32_t q_base, uint32_t* __restrict__ oq, uint32_t* __restrict__ osid,
+                                     int32_t* __restrict__ odelta, uint32_t* __restrict__ ocnt, uint32_t* __restrict__ odd) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nr) return;
+  const uint64_t val = v[rs[r]];
+  const uint32_t len = rs[r + 1] - rs[r];
+  const uint64_t grp = val >> (mb.dbits + 1);
+  oq[r] = q_base + (uint32_t)(grp >> mb.sb);
+  osid[r] = (uint32_t)(grp & ((1ull << mb.sb) - 1));
+  odelta[r] = (int32_t)((int64_t)((val >> 1) & ((1ull << mb.dbits) - 1)) - (int64_t)mb.bias);
+  ocnt[r] = len;
+  odd[r] = (val & 1) ? len : 0u;
+}
+
+// where shz_match_votes puts its records (device or host columns of `cap` entries)
+struct vote_sink {
+  uint32_t *q, *sid;
+  int32_t* delta;
+  uint32_t *cnt, *dd;
+  uint64_t cap, count;
+  bool device;
+};
+
+static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                          const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
+                          uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
+                          uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs, vote_sink* vs_out) {
   if (!ctx || !t) return SHZ_E_INVALID;
   if (t->ctx != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "table belongs to another ctx");
   if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
   if (n_queries == 0) return SHZ_OK;
-  if (!query_off || !out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres)
+  if (!query_off) SHZ_FAIL(ctx, SHZ_E_INVALID, "match: query_off is NULL");
+  if (!vs_out && (!out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres))
     SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_batch: NULL buffer");
-  if (topn < 1 || topn > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
+  if (!vs_out && (topn < 1 || topn > 64)) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   ctx->st_rows = ctx->st_pairs = ctx->st_keys = 0;
   const uint64_t P_BUDGET = 1ull << 28;
@@ -970,10 +996,9 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &tot));
     err = (char*)tot + 128;
     SHZ_HIP(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
-    uint32_t* h_nres = out_nres + q0;
     if (m == 0) {
       for (uint32_t q = 0; q < nq; ++q) {
-        h_nres[q] = 0;
+        if (out_nres) out_nres[q0 + q] = 0;
         if (out_nhash) out_nhash[q0 + q] = 0;
         if (out_npairs) out_npairs[q0 + q] = 0;
       }
@@ -1052,21 +1077,23 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
     if (out_nhash) SHZ_HIP(ctx, hipMemcpyAsync(out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_npairs) SHZ_HIP(ctx, hipMemcpyAsync(out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     // device result buffers
-    void *r_sid, *r_delta, *r_al, *r_dd, *r_n;
+    void *r_sid = nullptr, *r_delta = nullptr, *r_al = nullptr, *r_dd = nullptr, *r_n = nullptr;
     const uint64_t nres = (uint64_t)nq * topn;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, nres * 4, &r_dd));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)nq * 4, &r_n));
-    SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
-    SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
-    SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
-    SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
-    SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
+    if (!vs_out) {
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, nres * 4, &r_dd));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)nq * 4, &r_n));
+      SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
+      SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
+      SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
+      SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
+      SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
+    }
     if (P > 0) {
       // expand -> sort -> runs -> groups -> top-n.  E lives in one of SORT_A/B; the pair buffers use SORT_C/D.
-      void *v0, *v1, *rs, *gh, *gc, *gd, *gdd;
+      void *v0, *v1, *rs, *gh, *gd, *gdd;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
       hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
@@ -1085,28 +1112,68 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
       const uint32_t nr = (uint32_t)nr64;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
-      gc = nullptr;
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
       hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl,
                          (const uint32_t*)rps, P, (const uint64_t*)tot + 4, (uint32_t*)rs);
-      hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                         (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
-      hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                         (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
-                         (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
+      if (vs_out) {
+        // hand the runs over instead of folding them: five u32 columns staged in the workspace, then copied out
+        void* col[5];
+        const int slot[5] = {SHZ_WS_M2, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_PEAK_F, SHZ_WS_PEAK_T};
+        for (int i = 0; i < 5; ++i) SHZ_TRY(shz_ws_reserve(ctx, slot[i], (uint64_t)nr * 4, &col[i]));
+        hipLaunchKernelGGL(m_runs_export_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, q0,
+                           (uint32_t*)col[0], (uint32_t*)col[1], (int32_t*)col[2], (uint32_t*)col[3], (uint32_t*)col[4]);
+        SHZ_HIP(ctx, hipGetLastError());
+        if (vs_out->count + nr <= vs_out->cap) {
+          const hipMemcpyKind kd = vs_out->device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+          void* dst[5] = {vs_out->q, vs_out->sid, vs_out->delta, vs_out->cnt, vs_out->dd};
+          for (int i = 0; i < 5; ++i)
+            SHZ_HIP(ctx, hipMemcpyAsync((uint32_t*)dst[i] + vs_out->count, col[i], (uint64_t)nr * 4, kd, ctx->stream));
+        }
+        vs_out->count += nr;  // keeps counting past cap: the caller learns the size it needs
+      } else {
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
+        hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                           (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
+        hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                           (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
+                           (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
+      }
       SHZ_HIP(ctx, hipGetLastError());
     }
-    const uint64_t o0 = (uint64_t)q0 * topn;
-    SHZ_HIP(ctx, hipMemcpyAsync(out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!vs_out) {
+      const uint64_t o0 = (uint64_t)q0 * topn;
+      SHZ_HIP(ctx, hipMemcpyAsync(out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipMemcpyAsync(out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipMemcpyAsync(out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipMemcpyAsync(out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipMemcpyAsync(out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     q0 += nq;
   }
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                                   const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
+                                   uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
+                                   uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs) {
+  return match_core(ctx, t, key32, q_off, query_off, n_queries, topn, flags, out_sid, out_delta, out_aligned, out_dedup,
+                    out_nres, out_nhash, out_npairs, nullptr);
+}
+
+extern "C" int32_t shz_match_votes(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                                   const uint64_t* query_off, uint32_t n_queries, uint32_t flags, uint32_t* v_q,
+                                   uint32_t* v_sid, int32_t* v_delta, uint32_t* v_cnt, uint32_t* v_dedup, uint64_t cap,
+                                   uint64_t* count, uint32_t* out_nhash, uint64_t* out_npairs) {
+  if (!ctx || !count) return SHZ_E_INVALID;
+  if (cap && (!v_q || !v_sid || !v_delta || !v_cnt || !v_dedup)) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_votes: NULL column");
+  vote_sink sink{v_q, v_sid, v_delta, v_cnt, v_dedup, cap, 0, (flags & SHZ_OUT_DEVICE) != 0};
+  SHZ_TRY(match_core(ctx, t, key32, q_off, query_off, n_queries, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     out_nhash, out_npairs, &sink));
+  *count = sink.count;
+  if (sink.count > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_match_votes: %llu records, capacity %llu", (unsigned long long)sink.count, (unsigned long long)cap);
   return SHZ_OK;
 }
 
@@ -1115,5 +1182,315 @@ extern "C" int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_
   if (rows_scanned) *rows_scanned = ctx->st_rows;
   if (pairs) *pairs = ctx->st_pairs;
   if (distinct_keys) *distinct_keys = ctx->st_keys;
+  return SHZ_OK;
+}
+
+// ======================================================================================== key-sharded table
+// when the replicated table no longer fits one GPU's HBM, rows are partitioned by a hash
+// of the key.  A DB row lives on exactly one shard, so both quantities align_matches needs are additive over
+// shards: dedup_hashes[sid] (rows matched, recognizer.py:261-264) and counts[(sid, delta)] (recognizer.py:305).
+// Each shard votes on its own rows (shz_match_votes), the run records travel (shz_votes_allgather) and one
+// merge (shz_votes_merge) sums them and applies the reference's ranking.
+
+// shard of a key: a different multiplier and bit field than slice_of (segments inside a shard stay balanced)
+__host__ __device__ __forceinline__ uint32_t shard_of(uint32_t key, uint32_t nshards) {
+  return (((key ^ (key >> 15)) * 0x85EBCA6Bu) >> 10) % nshards;
+}
+
+__global__ void tbl_shard_flag_kernel(const uint32_t* __restrict__ key, uint64_t n, uint32_t nsh, uint32_t want,
+                                      uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = shard_of(key[i], nsh) == want ? 1u : 0u;
+}
+
+extern "C" int32_t shz_shard_of_keys(const uint32_t* key32, uint64_t n, uint32_t nshards, uint32_t* shard_out) {
+  if (!key32 || !shard_out || nshards == 0) return SHZ_E_INVALID;
+  for (uint64_t i = 0; i < n; ++i) shard_out[i] = shard_of(key32[i], nshards);
+  return SHZ_OK;
+}
+
+// compact the staged rows of shard `want` to (ok, os, oo); *cnt = how many
+static int32_t stage_select_shard(shz_table* t, uint32_t nsh, uint32_t want, uint32_t* ok, uint32_t* os, uint32_t* oo,
+                                  uint64_t* cnt) {
+  shz_ctx* ctx = t->ctx;
+  void *fl, *ps, *tot;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, t->ns * 4, &fl));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, t->ns * 4, &ps));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
+  hipLaunchKernelGGL(tbl_shard_flag_kernel, dim3(nblk(t->ns)), dim3(256), 0, ctx->stream, (const uint32_t*)t->skey, t->ns,
+                     nsh, want, (uint32_t*)fl);
+  SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, t->ns, (uint64_t*)tot));
+  hipLaunchKernelGGL(tbl_slice_scatter_kernel, dim3(nblk(t->ns)), dim3(256), 0, ctx->stream, (const uint32_t*)t->skey,
+                     (const uint32_t*)t->ssid, (const uint32_t*)t->soff, (const uint32_t*)fl, (const uint32_t*)ps, t->ns, ok,
+                     os, oo);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipMemcpyAsync(cnt, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t nshards) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (nshards == 0 || shard >= nshards) SHZ_FAIL(ctx, SHZ_E_INVALID, "keep_shard: shard %u of %u", shard, nshards);
+  if (t->ns == 0 || nshards == 1) return SHZ_OK;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t* g[3];
+  for (int i = 0; i < 3; ++i)
+    if (hipMalloc(&g[i], t->ns * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "keep_shard: hipMalloc(%llu) failed", (unsigned long long)(t->ns * 4));
+  uint64_t kept = 0;
+  SHZ_TRY(stage_select_shard(t, nshards, shard, g[0], g[1], g[2], &kept));
+  void* olds[] = {t->skey, t->ssid, t->soff};
+  for (void* p : olds) SHZ_HIP(ctx, hipFree(p));
+  t->skey = g[0]; t->ssid = g[1]; t->soff = g[2];
+  t->scap = t->ns;
+  t->ns = kept;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
+  if (!t || !c) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  int rank, nranks;
+  shz_comm_info(c, &rank, &nranks);
+  // 1) partition the staged rows by destination: the send columns hold the blocks for rank 0, 1, ... back to back
+  uint32_t* snd[3] = {nullptr, nullptr, nullptr};
+  const uint64_t ns = t->ns;
+  for (int i = 0; i < 3; ++i)
+    if (hipMalloc(&snd[i], std::max<uint64_t>(ns, 1) * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(ns * 4));
+  std::vector<uint64_t> scnt(nranks, 0), sdis(nranks, 0);
+  uint64_t pos = 0;
+  for (int d = 0; d < nranks && ns; ++d) {
+    uint64_t k = 0;
+    SHZ_TRY(stage_select_shard(t, (uint32_t)nranks, (uint32_t)d, snd[0] + pos, snd[1] + pos, snd[2] + pos, &k));
+    scnt[d] = k;
+    sdis[d] = pos;
+    pos += k;
+  }
+  // 2) everyone learns the whole count matrix: row r = what rank r sends to each destination
+  void* d_cnt;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * nranks * (nranks + 1), &d_cnt));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, scnt.data(), 8ull * nranks, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + nranks, 8ull * nranks));
+  std::vector<uint64_t> mat((size_t)nranks * nranks);
+  SHZ_HIP(ctx, hipMemcpyAsync(mat.data(), (uint64_t*)d_cnt + nranks, 8ull * nranks * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint64_t> rcnt(nranks), rdis(nranks);
+  uint64_t total = 0;
+  for (int r = 0; r < nranks; ++r) {
+    rcnt[r] = mat[(size_t)r * nranks + rank];
+    rdis[r] = total;
+    total += rcnt[r];
+  }
+  if (bytes_recv) *bytes_recv = (total - rcnt[rank]) * 12;
+  // 3) one grouped all-to-all per column
+  uint32_t* rcv[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < 3; ++i)
+    if (hipMalloc(&rcv[i], std::max<uint64_t>(total, 1) * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
+  std::vector<uint64_t> sb(nranks), sd(nranks), rb(nranks), rd(nranks);
+  for (int r = 0; r < nranks; ++r) { sb[r] = scnt[r] * 4; sd[r] = sdis[r] * 4; rb[r] = rcnt[r] * 4; rd[r] = rdis[r] * 4; }
+  for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_alltoallv_bytes(c, snd[i], sb.data(), sd.data(), rcv[i], rb.data(), rd.data()));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // 4) the received rows are this rank's shard: they replace the staged rows
+  void* olds[] = {t->skey, t->ssid, t->soff, snd[0], snd[1], snd[2]};
+  for (void* p : olds)
+    if (p) SHZ_HIP(ctx, hipFree(p));
+  t->skey = rcv[0]; t->ssid = rcv[1]; t->soff = rcv[2];
+  t->ns = total;
+  t->scap = std::max<uint64_t>(total, 1);
+  return shz_table_finalize(t);
+}
+
+// ---------------------------------------------------------------------------------------- votes: gather + merge
+extern "C" int32_t shz_votes_allgather(shz_comm* c, uint64_t n_local, const uint32_t* v_q, const uint32_t* v_sid,
+                                       const int32_t* v_delta, const uint32_t* v_cnt, const uint32_t* v_dedup, uint32_t* g_q,
+                                       uint32_t* g_sid, int32_t* g_delta, uint32_t* g_cnt, uint32_t* g_dedup, uint64_t cap,
+                                       uint64_t* n_total) {
+  if (!c || !n_total) return SHZ_E_INVALID;
+  int rank, nranks;
+  shz_comm_info(c, &rank, &nranks);
+  shz_ctx* ctx = shz_comm_ctx(c);
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void* d_cnt;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, &n_local, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
+  std::vector<uint64_t> cnt(nranks), bytes(nranks), displ(nranks);
+  SHZ_HIP(ctx, hipMemcpyAsync(cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t total = 0;
+  for (int r = 0; r < nranks; ++r) { displ[r] = total * 4; bytes[r] = cnt[r] * 4; total += cnt[r]; }
+  *n_total = total;
+  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_votes_allgather: %llu records, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+  if (total == 0) return SHZ_OK;
+  if (!g_q || !g_sid || !g_delta || !g_cnt || !g_dedup) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_allgather: NULL column");
+  const void* src[5] = {v_q, v_sid, v_delta, v_cnt, v_dedup};
+  void* dst[5] = {g_q, g_sid, g_delta, g_cnt, g_dedup};
+  for (int i = 0; i < 5; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, src[i], dst[i], bytes.data(), displ.data()));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+__global__ void vm_range_kernel(const uint32_t* __restrict__ q, const uint32_t* __restrict__ sid,
+                                const int32_t* __restrict__ delta, uint64_t n, uint32_t* __restrict__ mx /*[q, sid]*/,
+                                int32_t* __restrict__ dr /*[min, max]*/) {
+  uint32_t mq = 0, ms = 0;
+  int32_t lo = 0x7FFFFFFF, hi = -0x7FFFFFFF - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    mq = max(mq, q[i]);
+    ms = max(ms, sid[i]);
+    lo = min(lo, delta[i]);
+    hi = max(hi, delta[i]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    mq = max(mq, (uint32_t)__shfl_xor((int)mq, d, 64));
+    ms = max(ms, (uint32_t)__shfl_xor((int)ms, d, 64));
+    lo = min(lo, __shfl_xor(lo, d, 64));
+    hi = max(hi, __shfl_xor(hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&mx[0], mq);
+    atomicMax(&mx[1], ms);
+    atomicMin(&dr[0], lo);
+    atomicMax(&dr[1], hi);
+  }
+}
+
+__global__ void vm_compose_kernel(const uint32_t* __restrict__ q, const uint32_t* __restrict__ sid,
+                                  const int32_t* __restrict__ delta, const uint32_t* __restrict__ cnt,
+                                  const uint32_t* __restrict__ dd, uint64_t n, m_bits mb, uint64_t* __restrict__ key,
+                                  uint64_t* __restrict__ val) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t dprime = (uint64_t)((int64_t)delta[i] + (int64_t)mb.bias);
+  key[i] = ((((uint64_t)q[i] << mb.sb) | sid[i]) << mb.dbits | dprime) << 1;  // bit 0 stays clear: layout of m_topn_kernel
+  val[i] = ((uint64_t)dd[i] << 32) | cnt[i];
+}
+
+// one thread per record that opens a (query, sid) group: sum the records of equal delta (they come from different
+// shards or sub-batches), keep the first delta that reaches the largest sum, add up the dedup counts
+__global__ void vm_group_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ val, uint32_t n, m_bits mb,
+                                uint64_t* __restrict__ g_pack, uint32_t* __restrict__ g_delta,
+                                uint32_t* __restrict__ g_dedup) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int gshift = mb.dbits + 1;
+  const uint64_t grp = key[r] >> gshift;
+  const bool head = r == 0 || (key[r - 1] >> gshift) != grp;
+  if (!head) { g_pack[r] = 0; return; }
+  const uint64_t dmask = (1ull << mb.dbits) - 1;
+  uint32_t best = 0, bestd = 0, cur = 0, dedup = 0;
+  uint64_t curd = ~0ull;
+  for (uint32_t k = r; k < n; ++k) {
+    const uint64_t kv = key[k];
+    if ((kv >> gshift) != grp) break;
+    const uint64_t d = (kv >> 1) & dmask;
+    if (d != curd) {
+      if (cur > best) { best = cur; bestd = (uint32_t)curd; }
+      curd = d;
+      cur = 0;
+    }
+    cur += (uint32_t)val[k];
+    dedup += (uint32_t)(val[k] >> 32);
+  }
+  if (cur > best) { best = cur; bestd = (uint32_t)curd; }
+  const uint32_t sid = (uint32_t)(grp & ((1ull << mb.sb) - 1));
+  g_pack[r] = ((uint64_t)best << 32) | (0xFFFFFFFFu - sid);
+  g_delta[r] = bestd;
+  g_dedup[r] = dedup;
+}
+
+__global__ void vm_iota_kernel(uint32_t* __restrict__ p, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+extern "C" int32_t shz_votes_merge(shz_ctx* ctx, const uint32_t* v_q, const uint32_t* v_sid, const int32_t* v_delta,
+                                   const uint32_t* v_cnt, const uint32_t* v_dedup, uint64_t n, uint32_t n_queries,
+                                   uint32_t topn, uint32_t flags, uint32_t* out_sid, int32_t* out_delta,
+                                   uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (n_queries == 0) return SHZ_OK;
+  if (!out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: NULL output");
+  if (topn < 1 || topn > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
+  if (n >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_votes_merge: %llu records (limit 2^31); merge fewer queries per call", (unsigned long long)n);
+  const uint64_t nres = (uint64_t)n_queries * topn;
+  memset(out_sid, 0, nres * 4); memset(out_delta, 0, nres * 4); memset(out_aligned, 0, nres * 4);
+  memset(out_dedup, 0, nres * 4); memset(out_nres, 0, (uint64_t)n_queries * 4);
+  if (n == 0) return SHZ_OK;
+  if (!v_q || !v_sid || !v_delta || !v_cnt || !v_dedup) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: NULL column");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const void* col[5] = {v_q, v_sid, v_delta, v_cnt, v_dedup};
+  if (!(flags & SHZ_IN_DEVICE)) {
+    const int slot[5] = {SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7};
+    for (int i = 0; i < 5; ++i) {
+      void* d;
+      SHZ_TRY(shz_ws_reserve(ctx, slot[i], n * 4, &d));
+      SHZ_HIP(ctx, hipMemcpyAsync(d, col[i], n * 4, hipMemcpyHostToDevice, ctx->stream));
+      col[i] = d;
+    }
+  }
+  void* rg;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &rg));
+  const int32_t init[4] = {0, 0, 0x7FFFFFFF, -0x7FFFFFFF - 1};
+  SHZ_HIP(ctx, hipMemcpyAsync(rg, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(vm_range_kernel, dim3((unsigned)std::min<uint64_t>(nblk(n), 1024)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)col[0], (const uint32_t*)col[1], (const int32_t*)col[2], n, (uint32_t*)rg,
+                     (int32_t*)rg + 2);
+  SHZ_HIP(ctx, hipGetLastError());
+  int32_t hr[4];
+  SHZ_HIP(ctx, hipMemcpyAsync(hr, rg, 16, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((uint32_t)hr[0] >= n_queries) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: query index %u >= n_queries %u", (uint32_t)hr[0], n_queries);
+  m_bits mb;
+  mb.qb = bits_for(n_queries - 1);
+  mb.sb = bits_for((uint32_t)hr[1]);
+  mb.bias = hr[2] < 0 ? (uint32_t)(-(int64_t)hr[2]) : 0u;
+  mb.dbits = bits_for((uint64_t)((int64_t)hr[3] + (int64_t)mb.bias));
+  if (mb.qb + mb.sb + mb.dbits + 1 > 64) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_votes_merge: query/song/offset ranges need %d bits", mb.qb + mb.sb + mb.dbits + 1);
+  void *k0, *k1, *w0, *w1, *gh, *gd, *gdd, *rs;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &k1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, n * 8, &w0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * 8, &w1));
+  hipLaunchKernelGGL(vm_compose_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, (const uint32_t*)col[0],
+                     (const uint32_t*)col[1], (const int32_t*)col[2], (const uint32_t*)col[3], (const uint32_t*)col[4], n, mb,
+                     (uint64_t*)k0, (uint64_t*)w0);
+  SHZ_HIP(ctx, hipGetLastError());
+  int sel = 0;
+  SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)k0, (uint64_t*)k1, w0, w1, 8, n, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
+  const uint64_t* ks = sel ? (const uint64_t*)k1 : (const uint64_t*)k0;
+  const uint64_t* ws = sel ? (const uint64_t*)w1 : (const uint64_t*)w0;
+  const uint32_t nr = (uint32_t)n;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)nr * 8, &gh));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)nr * 4, &gd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 4, &gdd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, (uint64_t)(nr + 1) * 4, &rs));
+  hipLaunchKernelGGL(vm_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, ks, ws, nr, mb, (uint64_t*)gh, (uint32_t*)gd,
+                     (uint32_t*)gdd);
+  hipLaunchKernelGGL(vm_iota_kernel, dim3(nblk((uint64_t)nr + 1)), dim3(256), 0, ctx->stream, (uint32_t*)rs, nr + 1);
+  void *r_sid, *r_delta, *r_al, *r_dd, *r_n;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, nres * 4, &r_dd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)n_queries * 4, &r_n));
+  SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)n_queries * 4, ctx->stream));
+  hipLaunchKernelGGL(m_topn_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, ks, (const uint32_t*)rs, nr, mb,
+                     (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, n_queries, topn, (uint32_t*)r_sid,
+                     (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipMemcpyAsync(out_sid, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(out_delta, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(out_aligned, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(out_dedup, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemcpyAsync(out_nres, r_n, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }

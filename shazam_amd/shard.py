@@ -1,0 +1,185 @@
+"""Key-sharded fingerprints table: for databases larger than one GPU's HBM.
+
+Rows are partitioned by a hash of key32 (``shard_of_keys``).  A DB row ``(hash, song_id, offset)`` lives on
+exactly one shard, so what ``align_matches`` needs is a sum over shards: ``dedup_hashes[sid]`` counts DB rows
+(`recognizer.py:261-264`) and ``counts[(sid, offset difference)]`` counts matches (`recognizer.py:305`).
+Every shard votes on its own rows (``shz_match_votes``), the records are gathered, and one merge applies the
+reference's ranking (``shz_votes_merge``) -- the result equals ``Table.match`` on the unsharded table bit for bit
+(tests/test_gpu_shard.py).
+
+Two deployments share the code:
+* ``ShardedTable(ctx, nshards=S)``            -- S shards on one GPU (tests; a table split to bound sort scratch);
+* ``ShardedTable(ctx, comm=Comm(...))``       -- one shard per rank, rows routed by an RCCL all-to-all
+  (``shz_table_shard_exchange``), vote records collected by an all-gather (``shz_votes_allgather``).  All ranks
+  call ``match`` with the same queries (SPMD) and every rank gets the full result.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import E_CAPACITY, IN_DEVICE, OUT_DEVICE, lib, ptr, u64p
+
+VOTE_COLS = (("q", np.uint32), ("sid", np.uint32), ("delta", np.int32), ("cnt", np.uint32), ("dedup", np.uint32))
+
+
+def shard_of_keys(key32, nshards: int) -> np.ndarray:
+    """Shard index of each key: the library's function, evaluated on the host (no GPU needed)."""
+    k = np.ascontiguousarray(key32, np.uint32)
+    out = np.empty(len(k), np.uint32)
+    rc = lib().shz_shard_of_keys(ptr(k), len(k), int(nshards), ptr(out))
+    if rc != _ffi.OK:
+        raise _ffi.ShzError(rc, "shz_shard_of_keys: invalid arguments")
+    return out
+
+
+def shard_of_keys_numpy(key32, nshards: int) -> np.ndarray:
+    """numpy twin of ``shard_of`` in shz_table.hip (used by the CPU tests to pin the function)."""
+    k = np.asarray(key32, np.uint32)
+    h = ((k ^ (k >> np.uint32(15))).astype(np.uint64) * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    return ((h >> np.uint64(10)) % np.uint64(nshards)).astype(np.uint32)
+
+
+def match_votes(table: "_ffi.Table", key32, q_off, query_off, device: bool = False):
+    """Vote records of one (shard) table for CSR queries.  Returns (cols, n, nhash, npairs): host arrays, or
+    DevBufs when ``device`` (for the all-gather)."""
+    ctx = table.ctx
+    k = np.ascontiguousarray(key32, np.uint32)
+    o = np.ascontiguousarray(q_off, np.uint32)
+    qo = np.ascontiguousarray(query_off, np.uint64)
+    nq = len(qo) - 1
+    nhash, npairs = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+    cap = max(1024, 2 * len(k))
+    while True:
+        cnt = C.c_uint64()
+        if device:
+            cols = [ctx.alloc(cap * 4) for _ in VOTE_COLS]
+        else:
+            cols = [np.empty(cap, dt) for _, dt in VOTE_COLS]
+        rc = lib().shz_match_votes(ctx.h, table.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, OUT_DEVICE if device else 0,
+                                   *[ptr(c) for c in cols], cap, C.byref(cnt), ptr(nhash), ptr(npairs))
+        if rc == E_CAPACITY:
+            if device:
+                for c in cols:
+                    c.free()
+            cap = int(cnt.value)
+            continue
+        ctx.check(rc)
+        n = int(cnt.value)
+        if not device:
+            cols = [c[:n] for c in cols]
+        return cols, n, nhash, npairs
+
+
+def votes_merge(ctx: "_ffi.Context", cols, n: int, n_queries: int, topn: int = 2, device: bool = False):
+    """Sum the records of equal (query, song, difference) and rank like align_matches."""
+    res = {"sid": np.zeros((n_queries, topn), np.uint32), "delta": np.zeros((n_queries, topn), np.int32),
+           "aligned": np.zeros((n_queries, topn), np.uint32), "dedup": np.zeros((n_queries, topn), np.uint32),
+           "nres": np.zeros(n_queries, np.uint32)}
+    if n == 0:
+        cols = [None] * len(VOTE_COLS)
+    elif not device:
+        cols = [np.ascontiguousarray(c[:n], dt) for c, (_, dt) in zip(cols, VOTE_COLS)]
+    ctx.check(lib().shz_votes_merge(ctx.h, *[ptr(c) for c in cols], n, n_queries, topn, IN_DEVICE if device else 0,
+                                    ptr(res["sid"]), ptr(res["delta"]), ptr(res["aligned"]), ptr(res["dedup"]),
+                                    ptr(res["nres"])))
+    return res
+
+
+class ShardedTable:
+    """Fingerprints table partitioned by key.  Mirrors ``Table``'s insert / finalize / match surface."""
+
+    def __init__(self, ctx: "_ffi.Context", nshards: int = None, comm: "_ffi.Comm" = None):
+        if (nshards is None) == (comm is None):
+            raise ValueError("give either nshards (shards on this GPU) or comm (one shard per rank)")
+        self.ctx, self.comm = ctx, comm
+        self.nshards = comm.nranks if comm is not None else int(nshards)
+        if self.nshards < 1:
+            raise ValueError("nshards must be >= 1")
+        # with a communicator this rank holds one shard; otherwise all of them
+        self.tables = [_ffi.Table(ctx) for _ in range(1 if comm is not None else self.nshards)]
+        self.bytes_received = 0
+
+    def close(self):
+        for t in self.tables:
+            t.close()
+        self.tables = []
+
+    # -- build ---------------------------------------------------------------------------------
+    def insert(self, key32, sid, off):
+        """Stage rows (host arrays).  Local shards: routed now; with a communicator: routed at finalize."""
+        k = np.ascontiguousarray(key32, np.uint32)
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(sid, np.uint32), k.shape))
+        o = np.ascontiguousarray(off, np.uint32)
+        if self.comm is not None:
+            self.tables[0].insert(k, s, o)
+            return
+        sh = shard_of_keys(k, self.nshards)
+        for i, t in enumerate(self.tables):
+            m = sh == i
+            if m.any():
+                t.insert(k[m], s[m], o[m])
+
+    def insert_clips(self, key32, t1, hash_off, sid0, device=False):
+        """Stage the CSR output of fingerprint_batch (song id of clip c = sid0 + c)."""
+        if self.comm is not None:
+            self.tables[0].insert_clips(key32, t1, hash_off, sid0, device=device)
+            return
+        for i, t in enumerate(self.tables):  # every shard stages the batch on the device and keeps its slice
+            t.insert_clips(key32, t1, hash_off, sid0, device=device)
+            self.ctx.check(lib().shz_table_keep_shard(t.h, i, self.nshards))
+
+    def finalize(self):
+        if self.comm is not None:
+            b = C.c_uint64()
+            self.ctx.check(lib().shz_table_shard_exchange(self.tables[0].h, self.comm.h, C.byref(b)))
+            self.bytes_received += b.value
+        else:
+            for t in self.tables:
+                t.finalize()
+
+    def rows(self):
+        """(rows held here, staged rows held here)"""
+        r = [t.rows() for t in self.tables]
+        return sum(a for a, _ in r), sum(b for _, b in r)
+
+    # -- query ---------------------------------------------------------------------------------
+    def match(self, key32, q_off, query_off, topn=2):
+        """Same result dict as ``Table.match`` on the union of all shards."""
+        qo = np.ascontiguousarray(query_off, np.uint64)
+        nq = len(qo) - 1
+        ctx = self.ctx
+        if self.comm is None:
+            parts = [match_votes(t, key32, q_off, qo) for t in self.tables]
+            cols = [np.concatenate([p[0][c] for p in parts]) for c in range(len(VOTE_COLS))]
+            n = sum(p[1] for p in parts)
+            res = votes_merge(ctx, cols, n, nq, topn)
+            res["nhash"] = parts[0][2]                       # a property of the query alone
+            res["npairs"] = sum(p[3] for p in parts)         # matches add up over shards
+            return res
+        cols, n, nhash, npairs = match_votes(self.tables[0], key32, q_off, qo, device=True)
+        # counts first, then the records themselves
+        tot = C.c_uint64()
+        cap = None
+        gathered = None
+        while True:
+            if cap is None:
+                # a zero-capacity call returns the total through E_CAPACITY (or succeeds when there is nothing)
+                rc = lib().shz_votes_allgather(self.comm.h, n, *[ptr(c) for c in cols], None, None, None, None, None, 0,
+                                               C.byref(tot))
+                if rc == E_CAPACITY:
+                    cap = int(tot.value)
+                    continue
+                ctx.check(rc)
+                gathered, cap = [], 0
+                break
+            gathered = [ctx.alloc(max(cap, 1) * 4) for _ in VOTE_COLS]
+            ctx.check(lib().shz_votes_allgather(self.comm.h, n, *[ptr(c) for c in cols], *[ptr(g) for g in gathered], cap,
+                                                C.byref(tot)))
+            break
+        res = votes_merge(ctx, gathered, int(tot.value), nq, topn, device=True) if cap else votes_merge(ctx, [], 0, nq, topn)
+        for b in list(cols) + list(gathered):
+            b.free()
+        res["nhash"] = nhash
+        res["npairs"] = npairs  # this rank's share; sum over ranks = matches against the whole table
+        return res
