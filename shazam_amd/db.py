@@ -62,9 +62,15 @@ class HipFingerprintDB:
     SELECT_MULTIPLE = "SELECT HEX(`hash`), `song_id`, `offset` FROM `fingerprints` WHERE `hash` IN (%s);"
     IN_MATCH = "UNHEX(%s)"
 
-    def __init__(self, device: int | None = None, ctx: _ffi.Context = None, **options):
+    def __init__(self, device: int | None = None, ctx: _ffi.Context = None, shards: int = 1, **options):
+        """shards > 1: the rows are partitioned by key into that many tables on this GPU (shazam_amd/shard.py);
+        results are identical, each shard's sort scratch is 1/shards of the whole."""
         self.ctx = ctx or get_context(device)
-        self.table = _ffi.Table(self.ctx)
+        if int(shards) > 1:
+            from .shard import ShardedTable
+            self.table = ShardedTable(self.ctx, nshards=int(shards))
+        else:
+            self.table = _ffi.Table(self.ctx)
         self.songs = {}          # sid -> dict(song_name, file_sha1, total_hashes, fingerprinted, date_created)
         self._next_sid = 1       # AUTO_INCREMENT (mysql_database.py:34)
         self._dirty = False

@@ -183,3 +183,53 @@ class ShardedTable:
         res["nhash"] = nhash
         res["npairs"] = npairs  # this rank's share; sum over ranks = matches against the whole table
         return res
+
+    # -- the rest of Table's surface (shards on this GPU only) ------------------------------------
+    def _local_only(self, what):
+        if self.comm is not None:
+            raise NotImplementedError(f"{what} on a rank-sharded table needs a collective; only match() is distributed")
+
+    def set_segment_rows(self, rows: int):
+        for t in self.tables:
+            t.set_segment_rows(rows)
+
+    def lookup(self, keys):
+        """Rows of the listed keys, grouped in key-list order (a key lives on one shard)."""
+        self._local_only("lookup")
+        kk = np.ascontiguousarray(keys, np.uint32)
+        uniq = np.unique(kk)
+        sh = shard_of_keys(uniq, self.nshards)
+        rows = {}
+        for i, t in enumerate(self.tables):
+            mine = uniq[sh == i]
+            if len(mine) == 0:
+                continue
+            k, s, o = t.lookup(mine)                       # grouped by key in the (sorted, distinct) order given
+            cut = np.searchsorted(k, mine, side="left")    # k is non-decreasing here
+            end = np.searchsorted(k, mine, side="right")
+            for key, a, b in zip(mine.tolist(), cut.tolist(), end.tolist()):
+                rows[key] = (s[a:b], o[a:b])
+        ks, ss, os_ = [], [], []
+        for key in kk.tolist():
+            s, o = rows.get(key, (np.zeros(0, np.uint32), np.zeros(0, np.uint32)))
+            ks.append(np.full(len(s), key, np.uint32))
+            ss.append(s)
+            os_.append(o)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint32)  # noqa: E731
+        return cat(ks), cat(ss), cat(os_)
+
+    def export(self):
+        """All rows sorted by (key, sid, off), like Table.export."""
+        self._local_only("export")
+        parts = [t.export() for t in self.tables]
+        k, s, o = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        order = np.lexsort((o, s, k))
+        return k[order], s[order], o[order]
+
+    def song_rows(self, sid) -> int:
+        self._local_only("song_rows")
+        return sum(t.song_rows(sid) for t in self.tables)
+
+    def match_stats(self):
+        """Counters of the LAST shard's vote pass (rows scanned / pairs / distinct keys)."""
+        return self.tables[-1].match_stats()
