@@ -38,13 +38,19 @@ def main():
     ap.add_argument("--noise-amp", type=int, default=1500)
     ap.add_argument("--topn", type=int, default=2)
     ap.add_argument("--finalize-every", type=int, default=0, help="songs between intermediate finalize calls (0 = once at the end)")
+    ap.add_argument("--shards", type=int, default=1, help="partition the table by key into this many shards on the GPU "
+                    "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
     a = ap.parse_args()
 
     from shazam_amd import _ffi, Table
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     n_samples = int(round(a.seconds * FS))
     frames = int(_ffi.lib().shz_frame_count(n_samples))
-    tbl = Table(ctx)
+    if a.shards > 1:
+        from shazam_amd.shard import ShardedTable
+        tbl = ShardedTable(ctx, nshards=a.shards)
+    else:
+        tbl = Table(ctx)
     cap = a.chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
     pcm = ctx.alloc(a.chunk * n_samples * 2)
@@ -118,7 +124,7 @@ def main():
            "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
            "config": {"workload": f"{a.songs} x {a.seconds:.0f} s tonal+noise tracks in one HBM table; {nq} x "
                                   f"{a.query_seconds:.0f} s queries at arbitrary offsets, SNR {a.snr} dB, batches of {a.match_batch}",
-                      "songs": a.songs, "rows": int(rows), "queries": nq, "snr_db": a.snr},
+                      "songs": a.songs, "rows": int(rows), "queries": nq, "snr_db": a.snr, "shards": a.shards},
            "top1_accuracy": correct / nq, "hashes_per_query": tot_hash / nq, "pairs_per_query": tot_pairs / nq,
            "rows_scanned_per_query": tot_rows / nq, "query_fingerprint_ms": t_qfp / nq * 1e3,
            "match_alg_GBs": (8 * tot_rows) / t_match / 1e9,

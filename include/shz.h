@@ -207,6 +207,10 @@ int32_t shz_comm_barrier(shz_comm* c);
 int32_t shz_shard_of_keys(const uint32_t* key32, uint64_t n, uint32_t nshards, uint32_t* shard_out);
 /* drop the STAGED rows that do not belong to `shard` (several shards on one GPU, tests) */
 int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t nshards);
+/* append the STAGED rows of src that belong to `shard` to dst's staged rows (src unchanged), and forget a
+ * table's staged rows: one staging table feeding several shard tables on one GPU */
+int32_t shz_table_stage_from(shz_table* dst, shz_table* src, uint32_t shard, uint32_t nshards);
+int32_t shz_table_clear_staged(shz_table* t);
 /* route every rank's STAGED rows to the owner of their key, then finalize; bytes_recv: payload received */
 int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t* bytes_recv);
 /* The votes of the table's rows for the queries (same query layout as shz_match_batch), as records

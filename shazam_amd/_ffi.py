@@ -69,6 +69,8 @@ SIGNATURES = {
     "shz_shard_of_keys": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp]),
     "shz_table_keep_shard": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
     "shz_table_shard_exchange": (C.c_int32, [vp, vp, u64p]),
+    "shz_table_stage_from": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32]),
+    "shz_table_clear_staged": (C.c_int32, [vp]),
     "shz_match_votes": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, u64p,
                                     vp, vp]),
     "shz_votes_allgather": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, u64p]),

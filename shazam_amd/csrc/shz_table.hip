@@ -1494,3 +1494,25 @@ extern "C" int32_t shz_votes_merge(shz_ctx* ctx, const uint32_t* v_q, const uint
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
+
+// append the STAGED rows of `src` that belong to `shard` to the staged rows of `dst` (src is left untouched):
+// one staging table feeds several shard tables on the same GPU
+extern "C" int32_t shz_table_stage_from(shz_table* dst, shz_table* src, uint32_t shard, uint32_t nshards) {
+  if (!dst || !src) return SHZ_E_INVALID;
+  shz_ctx* ctx = dst->ctx;
+  if (src->ctx != ctx || src == dst) SHZ_FAIL(ctx, SHZ_E_INVALID, "stage_from: tables must differ and share a context");
+  if (nshards == 0 || shard >= nshards) SHZ_FAIL(ctx, SHZ_E_INVALID, "stage_from: shard %u of %u", shard, nshards);
+  if (src->ns == 0) return SHZ_OK;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_TRY(stage_reserve(dst, src->ns));  // upper bound; the selection writes behind dst's staged rows
+  uint64_t k = 0;
+  SHZ_TRY(stage_select_shard(src, nshards, shard, dst->skey + dst->ns, dst->ssid + dst->ns, dst->soff + dst->ns, &k));
+  dst->ns += k;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_clear_staged(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  t->ns = 0;
+  return SHZ_OK;
+}

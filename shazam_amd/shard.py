@@ -99,11 +99,16 @@ class ShardedTable:
         # with a communicator this rank holds one shard; otherwise all of them
         self.tables = [_ffi.Table(ctx) for _ in range(1 if comm is not None else self.nshards)]
         self.bytes_received = 0
+        self._stage = None       # staging table of insert_clips (shards on this GPU)
+        self._vcap = 0           # capacity of the device vote columns kept between match() calls
+        self._vcols = None
 
     def close(self):
-        for t in self.tables:
+        for t in self.tables + ([self._stage] if self._stage is not None else []):
             t.close()
-        self.tables = []
+        for b in self._vcols or []:
+            b.free()
+        self.tables, self._stage, self._vcols = [], None, None
 
     # -- build ---------------------------------------------------------------------------------
     def insert(self, key32, sid, off):
@@ -125,9 +130,12 @@ class ShardedTable:
         if self.comm is not None:
             self.tables[0].insert_clips(key32, t1, hash_off, sid0, device=device)
             return
-        for i, t in enumerate(self.tables):  # every shard stages the batch on the device and keeps its slice
-            t.insert_clips(key32, t1, hash_off, sid0, device=device)
-            self.ctx.check(lib().shz_table_keep_shard(t.h, i, self.nshards))
+        if self._stage is None:
+            self._stage = _ffi.Table(self.ctx)
+        self._stage.insert_clips(key32, t1, hash_off, sid0, device=device)   # expand once on the device ...
+        for i, t in enumerate(self.tables):                                  # ... and deal the rows out by key
+            self.ctx.check(lib().shz_table_stage_from(t.h, self._stage.h, i, self.nshards))
+        self.ctx.check(lib().shz_table_clear_staged(self._stage.h))
 
     def finalize(self):
         if self.comm is not None:
@@ -150,13 +158,7 @@ class ShardedTable:
         nq = len(qo) - 1
         ctx = self.ctx
         if self.comm is None:
-            parts = [match_votes(t, key32, q_off, qo) for t in self.tables]
-            cols = [np.concatenate([p[0][c] for p in parts]) for c in range(len(VOTE_COLS))]
-            n = sum(p[1] for p in parts)
-            res = votes_merge(ctx, cols, n, nq, topn)
-            res["nhash"] = parts[0][2]                       # a property of the query alone
-            res["npairs"] = sum(p[3] for p in parts)         # matches add up over shards
-            return res
+            return self._match_local(key32, q_off, qo, nq, topn)
         cols, n, nhash, npairs = match_votes(self.tables[0], key32, q_off, qo, device=True)
         # counts first, then the records themselves
         tot = C.c_uint64()
@@ -183,6 +185,42 @@ class ShardedTable:
         res["nhash"] = nhash
         res["npairs"] = npairs  # this rank's share; sum over ranks = matches against the whole table
         return res
+
+    def _match_local(self, key32, q_off, qo, nq, topn):
+        """Shards on this GPU: every shard appends its records to device columns, one merge reads them there."""
+        ctx = self.ctx
+        k = np.ascontiguousarray(key32, np.uint32)
+        o = np.ascontiguousarray(q_off, np.uint32)
+        nhash = np.zeros(nq, np.uint32)
+        if self._vcap == 0:
+            self._grow_votes(max(1 << 16, 4 * len(k)))
+        while True:
+            n, need, npairs = 0, 0, np.zeros(nq, np.uint64)
+            for t in self.tables:
+                cnt, np_s = C.c_uint64(), np.zeros(nq, np.uint64)
+                room = max(self._vcap - n, 0)
+                rc = lib().shz_match_votes(ctx.h, t.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, OUT_DEVICE,
+                                           *[ptr(b.ptr + 4 * n) for b in self._vcols], room, C.byref(cnt), ptr(nhash),
+                                           ptr(np_s))
+                if rc not in (_ffi.OK, E_CAPACITY):
+                    ctx.check(rc)
+                need += int(cnt.value)
+                if rc == _ffi.OK:
+                    n += int(cnt.value)
+                npairs += np_s
+            if need <= self._vcap:
+                break
+            self._grow_votes(need + need // 4)     # a shard did not fit: grow once and vote again
+        res = votes_merge(ctx, self._vcols, n, nq, topn, device=True)
+        res["nhash"] = nhash           # a property of the query alone
+        res["npairs"] = npairs         # matches add up over shards
+        return res
+
+    def _grow_votes(self, cap):
+        for b in self._vcols or []:
+            b.free()
+        self._vcols = [self.ctx.alloc(cap * 4) for _ in VOTE_COLS]
+        self._vcap = cap
 
     # -- the rest of Table's surface (shards on this GPU only) ------------------------------------
     def _local_only(self, what):
