@@ -548,7 +548,8 @@ extern "C" uint32_t shz_frame_count(uint64_t n) {
   return (uint32_t)((n - SHZ_NFFT) / SHZ_HOP + 1);
 }
 
-#define PK_SEG 252  // output frames per peak_pick workgroup (12 blocks of 21)
+#define PK_SEG 252       // output frames per peak_pick workgroup (12 blocks of 21) when workgroups are scarce
+#define PK_SEG_LONG 672  // ... and when the batch is large: 32 blocks, a 30 s clip in one piece (no time halo)
 
 struct sub_batch {
   uint32_t c0, c1;        // clips [c0, c1)
@@ -595,14 +596,19 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
   std::vector<uint64_t> soff(nc), len(nc);
   sd.foff.assign(nc + 1, 0);
   std::vector<peak_seg> segs;
+  // Each segment re-reads 10 halo frames on both sides (PMC: -4.6 % kernel time with whole-clip segments), but short
+  // segments keep the chip busy on small batches: go long once that still leaves >= 4 workgroups per slot.
+  const uint64_t slots = (uint64_t)ctx->prop.multiProcessorCount * 3;
+  const uint64_t n_slabs_ = (SHZ_NBINS + PK_SW - 1) / PK_SW;
+  const uint32_t seg_len = (uint64_t)sb.frames * n_slabs_ / PK_SEG_LONG >= 4 * slots ? PK_SEG_LONG : PK_SEG;
   for (uint32_t i = 0; i < nc; ++i) {
     const uint32_t c = sb.c0 + i;
     soff[i] = clip_off[c] - pcm_base_off;
     len[i] = clip_off[c + 1] - clip_off[c];
     const uint32_t f = shz_frame_count(len[i]);
     sd.foff[i + 1] = sd.foff[i] + f;
-    for (uint32_t t0 = 0; t0 < f; t0 += PK_SEG)
-      segs.push_back(peak_seg{sd.foff[i], f, t0, std::min(t0 + PK_SEG, f)});
+    for (uint32_t t0 = 0; t0 < f; t0 += seg_len)
+      segs.push_back(peak_seg{sd.foff[i], f, t0, std::min(t0 + seg_len, f)});
   }
   void *p0, *p1;
   const uint64_t meta_bytes = (uint64_t)nc * 16 + (uint64_t)(nc + 1) * 4 + 64;
