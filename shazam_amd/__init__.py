@@ -141,6 +141,8 @@ def _as_pcm(channel_samples) -> np.ndarray:
 
 
 def _check_window(wsize, wratio):
+    if int(int(wsize) * float(wratio)) >= int(wsize):   # what mlab.specgram raises for this call (mlab:242)
+        raise ValueError("noverlap must be less than NFFT")
     if int(wsize) != DEFAULT_WINDOW_SIZE or float(wratio) != DEFAULT_OVERLAP_RATIO:
         raise NotImplementedError("the HIP STFT kernel is built for wsize=4096, wratio=0.5 (the reference's "
                                   "only configuration); other windows are not implemented and there is no CPU fallback")
