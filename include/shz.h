@@ -201,8 +201,8 @@ int32_t shz_comm_barrier(shz_comm* c);
  * align_matches needs are sums over shards: dedup_hashes[sid] (recognizer.py:261-264) and the
  * (sid, offset difference) histogram (recognizer.py:305).  Build: every rank stages its own tracks' rows,
  * shz_table_shard_exchange routes each row to the rank that owns its key (all-to-all over RCCL) and
- * finalizes.  Query: every rank runs shz_match_votes on the same queries, shz_votes_allgather collects the
- * records, shz_votes_merge ranks them exactly like shz_match_batch on the unsharded table. */
+ * finalizes.  Query: every rank runs shz_match_pairs on the same queries, shz_pairs_allgather collects the
+ * packed votes, shz_pairs_vote ranks them: the same kernels as shz_match_batch on the unsharded table. */
 /* shard (0..nshards-1) of each key; host arrays */
 int32_t shz_shard_of_keys(const uint32_t* key32, uint64_t n, uint32_t nshards, uint32_t* shard_out);
 /* drop the STAGED rows that do not belong to `shard` (several shards on one GPU, tests) */
@@ -213,26 +213,32 @@ int32_t shz_table_stage_from(shz_table* dst, shz_table* src, uint32_t shard, uin
 int32_t shz_table_clear_staged(shz_table* t);
 /* route every rank's STAGED rows to the owner of their key, then finalize; bytes_recv: payload received */
 int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t* bytes_recv);
-/* The votes of the table's rows for the queries (same query layout as shz_match_batch), as records
- * (query, song_id, db_off - q_off, number of matches, of which DB rows counted once): columns of `cap`
- * entries on the host, or on the device with SHZ_OUT_DEVICE.  More than cap records: SHZ_E_CAPACITY
- * with *count = the number needed.  out_nhash / out_npairs as in shz_match_batch (may be NULL). */
-int32_t shz_match_votes(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+/* Votes travel packed, 8 bytes each, in ONE layout all shards agree on:
+ *   ((query << sid_bits | song_id) << delta_bits | (db_off - q_off) + bias) << 1 | counts-a-DB-row-once flag
+ * sid_bits >= bits of the largest song id of the WHOLE table, bias >= the largest q_off of the batch,
+ * delta_bits >= bits of (largest offset of the whole table + bias); bits(n_queries-1) + sid_bits + delta_bits + 1
+ * must fit 64.  shz_table_maxima gives a table's largest song id / offset (after shz_table_shard_exchange:
+ * of the whole sharded table). */
+int32_t shz_table_maxima(shz_table* t, uint32_t* max_sid, uint32_t* max_off);
+/* probe + expand only (the head of shz_match_batch): the votes of this table's rows for the queries, appended
+ * to a DEVICE buffer of cap entries.  More than cap: SHZ_E_CAPACITY with *count = the number needed.
+ * The table holds shard `shard` of `nshards` (1 shard: everything): only the query hashes that shard owns are
+ * looked up, so S shards together do the work of one table.
+ * out_nhash / out_npairs (host, may be NULL): per query the distinct hashes / matches found HERE -- both add up
+ * over shards, because every hash and every DB row belongs to exactly one of them. */
+int32_t shz_match_pairs(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
                         const uint64_t* query_off, uint32_t n_queries, uint32_t flags,
-                        uint32_t* v_q, uint32_t* v_sid, int32_t* v_delta, uint32_t* v_cnt, uint32_t* v_dedup,
-                        uint64_t cap, uint64_t* count, uint32_t* out_nhash, uint64_t* out_npairs);
-/* all-gather the ranks' vote records (device columns in, device columns of cap entries out) */
-int32_t shz_votes_allgather(shz_comm* c, uint64_t n_local, const uint32_t* v_q, const uint32_t* v_sid,
-                            const int32_t* v_delta, const uint32_t* v_cnt, const uint32_t* v_dedup,
-                            uint32_t* g_q, uint32_t* g_sid, int32_t* g_delta, uint32_t* g_cnt, uint32_t* g_dedup,
-                            uint64_t cap, uint64_t* n_total);
-/* sum the records of equal (query, song, difference) and rank per query like align_matches
- * (recognizer.py:289-338); records on the host, or on the device with SHZ_IN_DEVICE; outputs as in
- * shz_match_batch.  n < 2^31 records per call. */
-int32_t shz_votes_merge(shz_ctx* ctx, const uint32_t* v_q, const uint32_t* v_sid, const int32_t* v_delta,
-                        const uint32_t* v_cnt, const uint32_t* v_dedup, uint64_t n, uint32_t n_queries,
-                        uint32_t topn, uint32_t flags, uint32_t* out_sid, int32_t* out_delta,
-                        uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres);
+                        uint32_t shard, uint32_t nshards, uint32_t sid_bits, uint32_t delta_bits, uint32_t bias,
+                        uint64_t* d_pairs, uint64_t cap, uint64_t* count, uint32_t* out_nhash, uint64_t* out_npairs);
+/* all-gather the ranks' votes (device in, device buffer of cap entries out) */
+int32_t shz_pairs_allgather(shz_comm* c, uint64_t n_local, const uint64_t* d_pairs, uint64_t* d_all, uint64_t cap,
+                            uint64_t* n_total);
+/* the tail of shz_match_batch over any collection of votes in that layout: sort, run lengths, per (query, song)
+ * fold, top-n ranked like align_matches (recognizer.py:289-338).  d_pairs (device) is overwritten.  n < 2^32.
+ * Outputs (host) as in shz_match_batch. */
+int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, uint32_t n_queries, uint32_t sid_bits,
+                       uint32_t delta_bits, uint32_t bias, uint32_t topn, uint32_t* out_sid, int32_t* out_delta,
+                       uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres);
 
 #ifdef __cplusplus
 }

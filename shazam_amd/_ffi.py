@@ -71,11 +71,12 @@ SIGNATURES = {
     "shz_table_shard_exchange": (C.c_int32, [vp, vp, u64p]),
     "shz_table_stage_from": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32]),
     "shz_table_clear_staged": (C.c_int32, [vp]),
-    "shz_match_votes": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, u64p,
-                                    vp, vp]),
-    "shz_votes_allgather": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, u64p]),
-    "shz_votes_merge": (C.c_int32, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
-                                    vp, vp, vp, vp, vp]),
+    "shz_table_maxima": (C.c_int32, [vp, u32p, u32p]),
+    "shz_match_pairs": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p, vp, vp]),
+    "shz_pairs_allgather": (C.c_int32, [vp, C.c_uint64, vp, vp, C.c_uint64, u64p]),
+    "shz_pairs_vote": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   vp, vp, vp, vp, vp]),
 }
 
 

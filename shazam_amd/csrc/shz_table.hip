@@ -688,11 +688,22 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
 #define QIDX_SHIFT 52
 #define MAX_Q_SUB 4096
 
+// shard of a key: a different multiplier and bit field than slice_of (segments inside a shard stay balanced)
+__host__ __device__ __forceinline__ uint32_t shard_of(uint32_t key, uint32_t nshards) {
+  return (((key ^ (key >> 15)) * 0x85EBCA6Bu) >> 10) % nshards;
+}
+
 __global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint32_t* __restrict__ q_off,
                                  const uint64_t* __restrict__ query_off /*sub-batch CSR, nq+1*/, uint32_t nq, uint64_t m,
-                                 uint64_t* __restrict__ c, uint32_t* __restrict__ err) {
+                                 uint32_t nshards, uint32_t shard, uint64_t* __restrict__ c, uint32_t* __restrict__ err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // a shard only looks at the hashes it owns; the others collapse into ONE filler element behind the last query
+  // (index nq), which the host drops after the sort.  err[2] counts the owned elements.
+  const bool own = i < m && (nshards <= 1 || shard_of(key32[query_off[0] + i], nshards) == shard);
+  const unsigned long long ob = __ballot(own);
+  if ((threadIdx.x & 63) == 0 && ob) atomicAdd(err + 2, (uint32_t)__popcll(ob));
   if (i >= m) return;
+  if (!own) { c[i] = (uint64_t)nq << QIDX_SHIFT; return; }
   const uint64_t h = query_off[0] + i;
   uint32_t lo = 0, hi = nq;
   while (hi - lo > 1) {
@@ -795,7 +806,7 @@ struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset
 __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
                                 const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
                                 const uint32_t* __restrict__ g_rows, const shz_seg_dev* __restrict__ segs, int nseg,
-                                uint64_t P, m_bits mb, uint64_t* __restrict__ v) {
+                                uint64_t P, m_bits mb, uint32_t q_base, uint64_t* __restrict__ v) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   uint32_t l = 0, h = ng;  // last g with po[g] <= p
@@ -818,7 +829,7 @@ __global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* 
   const uint32_t* __restrict__ tsid = segs[sg].sid;
   const uint32_t* __restrict__ toff = segs[sg].off;
   const uint64_t e = E[e0 + oi];
-  const uint64_t q = e >> QIDX_SHIFT;
+  const uint64_t q = (e >> QIDX_SHIFT) + q_base;
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
   const uint64_t dprime = (uint64_t)toff[row] + mb.bias - qo;  // delta + bias >= 0
   v[p] = ((((q << mb.sb) | tsid[row]) << mb.dbits | dprime) << 1) | (oi == 0 ? 1u : 0u);
@@ -916,35 +927,50 @@ __global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict_
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-// one record per run of equal (query, sid, delta, first-offset flag) votes: the unit a key-sharded table hands over
-__global__ void m_runs_export_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs, uint32_t nr, m_bits mb,
-                                     uint32_t q_base, uint32_t* __restrict__ oq, uint32_t* __restrict__ osid,
-                                     int32_t* __restrict__ odelta, uint32_t* __restrict__ ocnt, uint32_t* __restrict__ odd) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nr) return;
-  const uint64_t val = v[rs[r]];
-  const uint32_t len = rs[r + 1] - rs[r];
-  const uint64_t grp = val >> (mb.dbits + 1);
-  oq[r] = q_base + (uint32_t)(grp >> mb.sb);
-  osid[r] = (uint32_t)(grp & ((1ull << mb.sb) - 1));
-  odelta[r] = (int32_t)((int64_t)((val >> 1) & ((1ull << mb.dbits) - 1)) - (int64_t)mb.bias);
-  ocnt[r] = len;
-  odd[r] = (val & 1) ? len : 0u;
-}
-
-// where shz_match_votes puts its records (device or host columns of `cap` entries)
-struct vote_sink {
-  uint32_t *q, *sid;
-  int32_t* delta;
-  uint32_t *cnt, *dd;
+// shz_match_pairs: the packed votes themselves leave match_core (device buffer of `cap` entries), in a key layout
+// the caller chose for ALL shards: ((q << sb | sid) << dbits | delta + bias) << 1 | first-offset flag, q global
+struct pair_sink {
+  uint64_t* d_pairs;
   uint64_t cap, count;
-  bool device;
+  m_bits lay;
+  uint32_t shard, nshards;  // nshards > 1: only the query hashes this shard owns are looked up
 };
+
+// sort the packed votes, run-length them, fold every (query, sid) group and pick the top-n per query into device
+// result arrays (r_*: nq*topn / nq entries, zeroed by the caller).  v0 holds the P votes, v1 is scratch of the same size.
+static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
+                         uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
+  int sel = 0;
+  SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
+  const uint64_t* vs = sel ? v1 : v0;
+  uint64_t* other = sel ? v0 : v1;  // free pair buffer: reuse for flags/positions (P*8 bytes = 2 x P u32)
+  uint32_t* rfl = (uint32_t*)other;
+  uint32_t* rps = rfl + P;
+  hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, vs, P, 0, rfl);
+  SHZ_TRY(shz_scan_u32(ctx, rfl, rps, P, d_tot));
+  uint64_t nr64 = 0;
+  SHZ_HIP(ctx, hipMemcpyAsync(&nr64, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t nr = (uint32_t)nr64;
+  void *rs, *gh, *gd, *gdd;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
+  hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl, (const uint32_t*)rps,
+                     P, (const uint64_t*)d_tot, (uint32_t*)rs);
+  hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (uint64_t*)gh,
+                     (uint32_t*)gd, (uint32_t*)gdd);
+  hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (const uint64_t*)gh,
+                     (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}
 
 static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
                           const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
                           uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
-                          uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs, vote_sink* vs_out) {
+                          uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs, pair_sink* vs_out) {
   if (!ctx || !t) return SHZ_E_INVALID;
   if (t->ctx != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "table belongs to another ctx");
   if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
@@ -1007,11 +1033,13 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     }
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, m * 8, &c0));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, m * 8, &c1));
+    const uint32_t f_nsh = vs_out ? vs_out->nshards : 1u, f_sh = vs_out ? vs_out->shard : 0u;
     hipLaunchKernelGGL(m_compose_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, d_key, d_qo, (const uint64_t*)d_qoff, nq,
-                       m, (uint64_t*)c0, (uint32_t*)err);
+                       m, f_nsh, f_sh, (uint64_t*)c0, (uint32_t*)err);
     SHZ_HIP(ctx, hipGetLastError());
     int sel = 0;
-    SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)c0, (uint64_t*)c1, nullptr, nullptr, 0, m, 0, QIDX_SHIFT + mb.qb, &sel));
+    SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)c0, (uint64_t*)c1, nullptr, nullptr, 0, m, 0,
+                         QIDX_SHIFT + (f_nsh > 1 ? bits_for(nq) : mb.qb), &sel));
     uint64_t* cs = sel ? (uint64_t*)c1 : (uint64_t*)c0;   // sorted
     uint64_t* E = sel ? (uint64_t*)c0 : (uint64_t*)c1;    // unique elements go to the other buffer
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, m * 4, &fl));
@@ -1023,14 +1051,27 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                        (const uint32_t*)fl, (const uint32_t*)ps, m, E);
     SHZ_HIP(ctx, hipGetLastError());
     uint64_t mu = 0;
-    uint32_t herr[2] = {0, 0};
+    uint32_t herr[3] = {0, 0, 0};
     SHZ_HIP(ctx, hipMemcpyAsync(&mu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(herr, err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(herr, err, 12, hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (herr[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
+    if (herr[2] < m) --mu;  // the filler element of the hashes other shards own sorts last: drop it
+    if (mu == 0) {          // nothing of this sub-batch belongs to this shard
+      for (uint32_t q = 0; q < nq; ++q) {
+        if (out_nhash) out_nhash[q0 + q] = 0;
+        if (out_npairs) out_npairs[q0 + q] = 0;
+      }
+      q0 += nq;
+      continue;
+    }
     mb.bias = herr[1];
     mb.dbits = bits_for((uint64_t)t->max_off + mb.bias);
-    if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
+    if (vs_out) {  // the caller's layout must hold this table's ids and offsets and these queries' offsets
+      const m_bits& L = vs_out->lay;
+      if (herr[1] > L.bias || bits_for(t->max_sid) > L.sb || bits_for((uint64_t)t->max_off + L.bias) > L.dbits)
+        SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_pairs: layout (sid_bits %d, delta_bits %d, bias %u) too small for this table / these queries", L.sb, L.dbits, L.bias);
+    } else if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
       if (nq > 1) { step = nq / 2; continue; }
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
     }
@@ -1091,55 +1132,26 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
       SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
     }
-    if (P > 0) {
+    if (P > 0 && vs_out) {
+      // hand the votes over: expand straight into the caller's buffer, in the shared layout, with global query indices
+      if (vs_out->count + P <= vs_out->cap) {
+        hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                           ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)grows, (const shz_seg_dev*)d_segs,
+                           nseg, P, vs_out->lay, q0, vs_out->d_pairs + vs_out->count);
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+      vs_out->count += P;  // keeps counting past cap: the caller learns the size it needs
+    } else if (P > 0) {
       // expand -> sort -> runs -> groups -> top-n.  E lives in one of SORT_A/B; the pair buffers use SORT_C/D.
-      void *v0, *v1, *rs, *gh, *gd, *gdd;
+      void *v0, *v1;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
       hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
                          ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)grows, (const shz_seg_dev*)d_segs,
-                         nseg, P, mb, (uint64_t*)v0);
+                         nseg, P, mb, 0u, (uint64_t*)v0);
       SHZ_HIP(ctx, hipGetLastError());
-      SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)v0, (uint64_t*)v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
-      const uint64_t* vs = sel ? (const uint64_t*)v1 : (const uint64_t*)v0;
-      void* other = sel ? v0 : v1;  // free pair buffer: reuse for flags/positions (P*8 bytes = 2 x P u32)
-      uint32_t* rfl = (uint32_t*)other;
-      uint32_t* rps = rfl + P;
-      hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, vs, P, 0, rfl);
-      SHZ_TRY(shz_scan_u32(ctx, rfl, rps, P, (uint64_t*)tot + 4));
-      uint64_t nr64 = 0;
-      SHZ_HIP(ctx, hipMemcpyAsync(&nr64, (uint64_t*)tot + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      const uint32_t nr = (uint32_t)nr64;
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
-      hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl,
-                         (const uint32_t*)rps, P, (const uint64_t*)tot + 4, (uint32_t*)rs);
-      if (vs_out) {
-        // hand the runs over instead of folding them: five u32 columns staged in the workspace, then copied out
-        void* col[5];
-        const int slot[5] = {SHZ_WS_M2, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_PEAK_F, SHZ_WS_PEAK_T};
-        for (int i = 0; i < 5; ++i) SHZ_TRY(shz_ws_reserve(ctx, slot[i], (uint64_t)nr * 4, &col[i]));
-        hipLaunchKernelGGL(m_runs_export_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, q0,
-                           (uint32_t*)col[0], (uint32_t*)col[1], (int32_t*)col[2], (uint32_t*)col[3], (uint32_t*)col[4]);
-        SHZ_HIP(ctx, hipGetLastError());
-        if (vs_out->count + nr <= vs_out->cap) {
-          const hipMemcpyKind kd = vs_out->device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-          void* dst[5] = {vs_out->q, vs_out->sid, vs_out->delta, vs_out->cnt, vs_out->dd};
-          for (int i = 0; i < 5; ++i)
-            SHZ_HIP(ctx, hipMemcpyAsync((uint32_t*)dst[i] + vs_out->count, col[i], (uint64_t)nr * 4, kd, ctx->stream));
-        }
-        vs_out->count += nr;  // keeps counting past cap: the caller learns the size it needs
-      } else {
-        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
-        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
-        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
-        hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                           (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
-        hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
-                           (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn,
-                           (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
-      }
-      SHZ_HIP(ctx, hipGetLastError());
+      SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, (uint64_t*)tot + 4, (uint32_t*)r_sid,
+                        (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
     }
     if (!vs_out) {
       const uint64_t o0 = (uint64_t)q0 * topn;
@@ -1163,17 +1175,28 @@ extern "C" int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* k
                     out_nres, out_nhash, out_npairs, nullptr);
 }
 
-extern "C" int32_t shz_match_votes(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
-                                   const uint64_t* query_off, uint32_t n_queries, uint32_t flags, uint32_t* v_q,
-                                   uint32_t* v_sid, int32_t* v_delta, uint32_t* v_cnt, uint32_t* v_dedup, uint64_t cap,
-                                   uint64_t* count, uint32_t* out_nhash, uint64_t* out_npairs) {
+extern "C" int32_t shz_table_maxima(shz_table* t, uint32_t* max_sid, uint32_t* max_off) {
+  if (!t) return SHZ_E_INVALID;
+  if (max_sid) *max_sid = t->max_sid;
+  if (max_off) *max_off = t->max_off;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_match_pairs(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
+                                   const uint64_t* query_off, uint32_t n_queries, uint32_t flags, uint32_t shard,
+                                   uint32_t nshards, uint32_t sid_bits, uint32_t delta_bits, uint32_t bias,
+                                   uint64_t* d_pairs, uint64_t cap, uint64_t* count, uint32_t* out_nhash,
+                                   uint64_t* out_npairs) {
   if (!ctx || !count) return SHZ_E_INVALID;
-  if (cap && (!v_q || !v_sid || !v_delta || !v_cnt || !v_dedup)) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_votes: NULL column");
-  vote_sink sink{v_q, v_sid, v_delta, v_cnt, v_dedup, cap, 0, (flags & SHZ_OUT_DEVICE) != 0};
+  if (cap && !d_pairs) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_pairs: NULL buffer");
+  if (nshards == 0 || shard >= nshards) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_pairs: shard %u of %u", shard, nshards);
+  if (sid_bits < 1 || delta_bits < 1 || bits_for(n_queries ? n_queries - 1 : 0) + sid_bits + delta_bits + 1 > 64)
+    SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_match_pairs: %u queries x %u sid bits x %u delta bits do not fit 64 bits", n_queries, sid_bits, delta_bits);
+  pair_sink sink{d_pairs, cap, 0, m_bits{(int)sid_bits, (int)delta_bits, 0, bias}, shard, nshards};
   SHZ_TRY(match_core(ctx, t, key32, q_off, query_off, n_queries, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr,
                      out_nhash, out_npairs, &sink));
   *count = sink.count;
-  if (sink.count > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_match_votes: %llu records, capacity %llu", (unsigned long long)sink.count, (unsigned long long)cap);
+  if (sink.count > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_match_pairs: %llu votes, capacity %llu", (unsigned long long)sink.count, (unsigned long long)cap);
   return SHZ_OK;
 }
 
@@ -1189,13 +1212,9 @@ extern "C" int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_
 // when the replicated table no longer fits one GPU's HBM, rows are partitioned by a hash
 // of the key.  A DB row lives on exactly one shard, so both quantities align_matches needs are additive over
 // shards: dedup_hashes[sid] (rows matched, recognizer.py:261-264) and counts[(sid, delta)] (recognizer.py:305).
-// Each shard votes on its own rows (shz_match_votes), the run records travel (shz_votes_allgather) and one
-// merge (shz_votes_merge) sums them and applies the reference's ranking.
-
-// shard of a key: a different multiplier and bit field than slice_of (segments inside a shard stay balanced)
-__host__ __device__ __forceinline__ uint32_t shard_of(uint32_t key, uint32_t nshards) {
-  return (((key ^ (key >> 15)) * 0x85EBCA6Bu) >> 10) % nshards;
-}
+// Each shard probes its own rows and emits their votes packed in one agreed layout (shz_match_pairs), the votes
+// travel (shz_pairs_allgather, 8 bytes each) and the normal tail of the match -- one sort, run lengths, per-group
+// fold, top-n -- runs once over all of them (shz_pairs_vote).
 
 __global__ void tbl_shard_flag_kernel(const uint32_t* __restrict__ key, uint64_t n, uint32_t nsh, uint32_t want,
                                       uint32_t* __restrict__ flag) {
@@ -1299,13 +1318,24 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   t->skey = rcv[0]; t->ssid = rcv[1]; t->soff = rcv[2];
   t->ns = total;
   t->scap = std::max<uint64_t>(total, 1);
-  return shz_table_finalize(t);
+  SHZ_TRY(shz_table_finalize(t));
+  // every shard packs its votes in one layout: agree on the largest song id / offset of the whole table
+  uint32_t mx[2] = {t->max_sid, t->max_off};
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
+  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, mx, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
+  std::vector<uint32_t> all(2 * (size_t)nranks);
+  SHZ_HIP(ctx, hipMemcpyAsync(all.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < nranks; ++r) {
+    t->max_sid = std::max(t->max_sid, all[2 * r]);
+    t->max_off = std::max(t->max_off, all[2 * r + 1]);
+  }
+  return SHZ_OK;
 }
 
-// ---------------------------------------------------------------------------------------- votes: gather + merge
-extern "C" int32_t shz_votes_allgather(shz_comm* c, uint64_t n_local, const uint32_t* v_q, const uint32_t* v_sid,
-                                       const int32_t* v_delta, const uint32_t* v_cnt, const uint32_t* v_dedup, uint32_t* g_q,
-                                       uint32_t* g_sid, int32_t* g_delta, uint32_t* g_cnt, uint32_t* g_dedup, uint64_t cap,
+// ---------------------------------------------------------------------------------------- votes: gather + rank
+extern "C" int32_t shz_pairs_allgather(shz_comm* c, uint64_t n_local, const uint64_t* d_pairs, uint64_t* d_all, uint64_t cap,
                                        uint64_t* n_total) {
   if (!c || !n_total) return SHZ_E_INVALID;
   int rank, nranks;
@@ -1320,158 +1350,35 @@ extern "C" int32_t shz_votes_allgather(shz_comm* c, uint64_t n_local, const uint
   SHZ_HIP(ctx, hipMemcpyAsync(cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint64_t total = 0;
-  for (int r = 0; r < nranks; ++r) { displ[r] = total * 4; bytes[r] = cnt[r] * 4; total += cnt[r]; }
+  for (int r = 0; r < nranks; ++r) { displ[r] = total * 8; bytes[r] = cnt[r] * 8; total += cnt[r]; }
   *n_total = total;
-  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_votes_allgather: %llu records, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_pairs_allgather: %llu votes, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
   if (total == 0) return SHZ_OK;
-  if (!g_q || !g_sid || !g_delta || !g_cnt || !g_dedup) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_allgather: NULL column");
-  const void* src[5] = {v_q, v_sid, v_delta, v_cnt, v_dedup};
-  void* dst[5] = {g_q, g_sid, g_delta, g_cnt, g_dedup};
-  for (int i = 0; i < 5; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, src[i], dst[i], bytes.data(), displ.data()));
+  if (!d_all || (n_local && !d_pairs)) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_pairs_allgather: NULL buffer");
+  SHZ_TRY(shz_comm_allgatherv_bytes(c, d_pairs, d_all, bytes.data(), displ.data()));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
 
-__global__ void vm_range_kernel(const uint32_t* __restrict__ q, const uint32_t* __restrict__ sid,
-                                const int32_t* __restrict__ delta, uint64_t n, uint32_t* __restrict__ mx /*[q, sid]*/,
-                                int32_t* __restrict__ dr /*[min, max]*/) {
-  uint32_t mq = 0, ms = 0;
-  int32_t lo = 0x7FFFFFFF, hi = -0x7FFFFFFF - 1;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    mq = max(mq, q[i]);
-    ms = max(ms, sid[i]);
-    lo = min(lo, delta[i]);
-    hi = max(hi, delta[i]);
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    mq = max(mq, (uint32_t)__shfl_xor((int)mq, d, 64));
-    ms = max(ms, (uint32_t)__shfl_xor((int)ms, d, 64));
-    lo = min(lo, __shfl_xor(lo, d, 64));
-    hi = max(hi, __shfl_xor(hi, d, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(&mx[0], mq);
-    atomicMax(&mx[1], ms);
-    atomicMin(&dr[0], lo);
-    atomicMax(&dr[1], hi);
-  }
-}
-
-__global__ void vm_compose_kernel(const uint32_t* __restrict__ q, const uint32_t* __restrict__ sid,
-                                  const int32_t* __restrict__ delta, const uint32_t* __restrict__ cnt,
-                                  const uint32_t* __restrict__ dd, uint64_t n, m_bits mb, uint64_t* __restrict__ key,
-                                  uint64_t* __restrict__ val) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t dprime = (uint64_t)((int64_t)delta[i] + (int64_t)mb.bias);
-  key[i] = ((((uint64_t)q[i] << mb.sb) | sid[i]) << mb.dbits | dprime) << 1;  // bit 0 stays clear: layout of m_topn_kernel
-  val[i] = ((uint64_t)dd[i] << 32) | cnt[i];
-}
-
-// one thread per record that opens a (query, sid) group: sum the records of equal delta (they come from different
-// shards or sub-batches), keep the first delta that reaches the largest sum, add up the dedup counts
-__global__ void vm_group_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ val, uint32_t n, m_bits mb,
-                                uint64_t* __restrict__ g_pack, uint32_t* __restrict__ g_delta,
-                                uint32_t* __restrict__ g_dedup) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const int gshift = mb.dbits + 1;
-  const uint64_t grp = key[r] >> gshift;
-  const bool head = r == 0 || (key[r - 1] >> gshift) != grp;
-  if (!head) { g_pack[r] = 0; return; }
-  const uint64_t dmask = (1ull << mb.dbits) - 1;
-  uint32_t best = 0, bestd = 0, cur = 0, dedup = 0;
-  uint64_t curd = ~0ull;
-  for (uint32_t k = r; k < n; ++k) {
-    const uint64_t kv = key[k];
-    if ((kv >> gshift) != grp) break;
-    const uint64_t d = (kv >> 1) & dmask;
-    if (d != curd) {
-      if (cur > best) { best = cur; bestd = (uint32_t)curd; }
-      curd = d;
-      cur = 0;
-    }
-    cur += (uint32_t)val[k];
-    dedup += (uint32_t)(val[k] >> 32);
-  }
-  if (cur > best) { best = cur; bestd = (uint32_t)curd; }
-  const uint32_t sid = (uint32_t)(grp & ((1ull << mb.sb) - 1));
-  g_pack[r] = ((uint64_t)best << 32) | (0xFFFFFFFFu - sid);
-  g_delta[r] = bestd;
-  g_dedup[r] = dedup;
-}
-
-__global__ void vm_iota_kernel(uint32_t* __restrict__ p, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
-}
-
-extern "C" int32_t shz_votes_merge(shz_ctx* ctx, const uint32_t* v_q, const uint32_t* v_sid, const int32_t* v_delta,
-                                   const uint32_t* v_cnt, const uint32_t* v_dedup, uint64_t n, uint32_t n_queries,
-                                   uint32_t topn, uint32_t flags, uint32_t* out_sid, int32_t* out_delta,
-                                   uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres) {
+extern "C" int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, uint32_t n_queries, uint32_t sid_bits,
+                                  uint32_t delta_bits, uint32_t bias, uint32_t topn, uint32_t* out_sid, int32_t* out_delta,
+                                  uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres) {
   if (!ctx) return SHZ_E_INVALID;
   if (n_queries == 0) return SHZ_OK;
-  if (!out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: NULL output");
+  if (!out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_pairs_vote: NULL output");
   if (topn < 1 || topn > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
-  if (n >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_votes_merge: %llu records (limit 2^31); merge fewer queries per call", (unsigned long long)n);
+  if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_pairs_vote: %llu votes (limit 2^32); vote fewer queries per call", (unsigned long long)n);
+  m_bits mb{(int)sid_bits, (int)delta_bits, bits_for(n_queries - 1), bias};
+  if (sid_bits < 1 || delta_bits < 1 || mb.qb + mb.sb + mb.dbits + 1 > 64) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_pairs_vote: key layout does not fit 64 bits");
   const uint64_t nres = (uint64_t)n_queries * topn;
   memset(out_sid, 0, nres * 4); memset(out_delta, 0, nres * 4); memset(out_aligned, 0, nres * 4);
   memset(out_dedup, 0, nres * 4); memset(out_nres, 0, (uint64_t)n_queries * 4);
   if (n == 0) return SHZ_OK;
-  if (!v_q || !v_sid || !v_delta || !v_cnt || !v_dedup) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: NULL column");
+  if (!d_pairs) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_pairs_vote: NULL votes");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  const void* col[5] = {v_q, v_sid, v_delta, v_cnt, v_dedup};
-  if (!(flags & SHZ_IN_DEVICE)) {
-    const int slot[5] = {SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7};
-    for (int i = 0; i < 5; ++i) {
-      void* d;
-      SHZ_TRY(shz_ws_reserve(ctx, slot[i], n * 4, &d));
-      SHZ_HIP(ctx, hipMemcpyAsync(d, col[i], n * 4, hipMemcpyHostToDevice, ctx->stream));
-      col[i] = d;
-    }
-  }
-  void* rg;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &rg));
-  const int32_t init[4] = {0, 0, 0x7FFFFFFF, -0x7FFFFFFF - 1};
-  SHZ_HIP(ctx, hipMemcpyAsync(rg, init, 16, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(vm_range_kernel, dim3((unsigned)std::min<uint64_t>(nblk(n), 1024)), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)col[0], (const uint32_t*)col[1], (const int32_t*)col[2], n, (uint32_t*)rg,
-                     (int32_t*)rg + 2);
-  SHZ_HIP(ctx, hipGetLastError());
-  int32_t hr[4];
-  SHZ_HIP(ctx, hipMemcpyAsync(hr, rg, 16, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if ((uint32_t)hr[0] >= n_queries) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_votes_merge: query index %u >= n_queries %u", (uint32_t)hr[0], n_queries);
-  m_bits mb;
-  mb.qb = bits_for(n_queries - 1);
-  mb.sb = bits_for((uint32_t)hr[1]);
-  mb.bias = hr[2] < 0 ? (uint32_t)(-(int64_t)hr[2]) : 0u;
-  mb.dbits = bits_for((uint64_t)((int64_t)hr[3] + (int64_t)mb.bias));
-  if (mb.qb + mb.sb + mb.dbits + 1 > 64) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_votes_merge: query/song/offset ranges need %d bits", mb.qb + mb.sb + mb.dbits + 1);
-  void *k0, *k1, *w0, *w1, *gh, *gd, *gdd, *rs;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &k1));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, n * 8, &w0));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * 8, &w1));
-  hipLaunchKernelGGL(vm_compose_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, (const uint32_t*)col[0],
-                     (const uint32_t*)col[1], (const int32_t*)col[2], (const uint32_t*)col[3], (const uint32_t*)col[4], n, mb,
-                     (uint64_t*)k0, (uint64_t*)w0);
-  SHZ_HIP(ctx, hipGetLastError());
-  int sel = 0;
-  SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)k0, (uint64_t*)k1, w0, w1, 8, n, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
-  const uint64_t* ks = sel ? (const uint64_t*)k1 : (const uint64_t*)k0;
-  const uint64_t* ws = sel ? (const uint64_t*)w1 : (const uint64_t*)w0;
-  const uint32_t nr = (uint32_t)n;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)nr * 8, &gh));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)nr * 4, &gd));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 4, &gdd));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, (uint64_t)(nr + 1) * 4, &rs));
-  hipLaunchKernelGGL(vm_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, ks, ws, nr, mb, (uint64_t*)gh, (uint32_t*)gd,
-                     (uint32_t*)gdd);
-  hipLaunchKernelGGL(vm_iota_kernel, dim3(nblk((uint64_t)nr + 1)), dim3(256), 0, ctx->stream, (uint32_t*)rs, nr + 1);
-  void *r_sid, *r_delta, *r_al, *r_dd, *r_n;
+  void *v1, *tot, *r_sid, *r_delta, *r_al, *r_dd, *r_n;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * 8, &v1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &tot));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
@@ -1482,10 +1389,8 @@ extern "C" int32_t shz_votes_merge(shz_ctx* ctx, const uint32_t* v_q, const uint
   SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)n_queries * 4, ctx->stream));
-  hipLaunchKernelGGL(m_topn_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, ks, (const uint32_t*)rs, nr, mb,
-                     (const uint64_t*)gh, (const uint32_t*)gd, (const uint32_t*)gdd, n_queries, topn, (uint32_t*)r_sid,
-                     (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n);
-  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_TRY(vote_tail(ctx, d_pairs, (uint64_t*)v1, n, n_queries, mb, topn, (uint64_t*)tot, (uint32_t*)r_sid, (int32_t*)r_delta,
+                    (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
   SHZ_HIP(ctx, hipMemcpyAsync(out_sid, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipMemcpyAsync(out_delta, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipMemcpyAsync(out_aligned, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));

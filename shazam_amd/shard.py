@@ -3,24 +3,23 @@
 Rows are partitioned by a hash of key32 (``shard_of_keys``).  A DB row ``(hash, song_id, offset)`` lives on
 exactly one shard, so what ``align_matches`` needs is a sum over shards: ``dedup_hashes[sid]`` counts DB rows
 (`recognizer.py:261-264`) and ``counts[(sid, offset difference)]`` counts matches (`recognizer.py:305`).
-Every shard votes on its own rows (``shz_match_votes``), the records are gathered, and one merge applies the
-reference's ranking (``shz_votes_merge``) -- the result equals ``Table.match`` on the unsharded table bit for bit
-(tests/test_gpu_shard.py).
+A shard looks up only the query hashes it owns and emits the votes of its rows, 8 bytes each, in a key layout all
+shards share (``shz_match_pairs``); the votes are gathered and the normal tail of the match -- one sort, run
+lengths, per-(query, song) fold, top-n -- runs once over all of them (``shz_pairs_vote``).  These are the kernels
+of ``Table.match``, so the result equals the unsharded table's bit for bit (tests/test_gpu_shard.py).
 
 Two deployments share the code:
 * ``ShardedTable(ctx, nshards=S)``            -- S shards on one GPU (tests; a table split to bound sort scratch);
 * ``ShardedTable(ctx, comm=Comm(...))``       -- one shard per rank, rows routed by an RCCL all-to-all
-  (``shz_table_shard_exchange``), vote records collected by an all-gather (``shz_votes_allgather``).  All ranks
-  call ``match`` with the same queries (SPMD) and every rank gets the full result.
+  (``shz_table_shard_exchange``), votes collected by an all-gather (``shz_pairs_allgather``).  All ranks call
+  ``match`` with the same queries (SPMD) and every rank gets the full result.
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _ffi
-from ._ffi import E_CAPACITY, IN_DEVICE, OUT_DEVICE, lib, ptr, u64p
-
-VOTE_COLS = (("q", np.uint32), ("sid", np.uint32), ("delta", np.int32), ("cnt", np.uint32), ("dedup", np.uint32))
+from ._ffi import E_CAPACITY, IN_DEVICE, lib, ptr, u64p
 
 
 def shard_of_keys(key32, nshards: int) -> np.ndarray:
@@ -40,49 +39,35 @@ def shard_of_keys_numpy(key32, nshards: int) -> np.ndarray:
     return ((h >> np.uint64(10)) % np.uint64(nshards)).astype(np.uint32)
 
 
-def match_votes(table: "_ffi.Table", key32, q_off, query_off, device: bool = False):
-    """Vote records of one (shard) table for CSR queries.  Returns (cols, n, nhash, npairs): host arrays, or
-    DevBufs when ``device`` (for the all-gather)."""
-    ctx = table.ctx
-    k = np.ascontiguousarray(key32, np.uint32)
-    o = np.ascontiguousarray(q_off, np.uint32)
-    qo = np.ascontiguousarray(query_off, np.uint64)
-    nq = len(qo) - 1
-    nhash, npairs = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
-    cap = max(1024, 2 * len(k))
-    while True:
-        cnt = C.c_uint64()
-        if device:
-            cols = [ctx.alloc(cap * 4) for _ in VOTE_COLS]
-        else:
-            cols = [np.empty(cap, dt) for _, dt in VOTE_COLS]
-        rc = lib().shz_match_votes(ctx.h, table.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, OUT_DEVICE if device else 0,
-                                   *[ptr(c) for c in cols], cap, C.byref(cnt), ptr(nhash), ptr(npairs))
-        if rc == E_CAPACITY:
-            if device:
-                for c in cols:
-                    c.free()
-            cap = int(cnt.value)
-            continue
-        ctx.check(rc)
-        n = int(cnt.value)
-        if not device:
-            cols = [c[:n] for c in cols]
-        return cols, n, nhash, npairs
+def _bits(v: int) -> int:
+    return max(1, int(v).bit_length())
 
 
-def votes_merge(ctx: "_ffi.Context", cols, n: int, n_queries: int, topn: int = 2, device: bool = False):
-    """Sum the records of equal (query, song, difference) and rank like align_matches."""
+def table_maxima(table: "_ffi.Table"):
+    """(largest song id, largest offset) of a finalized table -- they size the packed vote key."""
+    a, b = C.c_uint32(), C.c_uint32()
+    table.ctx.check(lib().shz_table_maxima(table.h, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def vote_layout(max_sid: int, max_off: int, q_off, n_queries: int):
+    """(sid_bits, delta_bits, bias) every shard packs its votes with; raises if the key does not fit 64 bits."""
+    q_off = np.asarray(q_off)
+    bias = int(q_off.max()) if q_off.size else 0
+    sid_bits, delta_bits = _bits(max_sid), _bits(max_off + bias)
+    if _bits(max(n_queries - 1, 0)) + sid_bits + delta_bits + 1 > 64:
+        raise _ffi.ShzError(_ffi.E_UNSUPPORTED, f"{n_queries} queries x {sid_bits} song-id bits x {delta_bits} offset bits "
+                                                "do not fit the 64-bit vote key; match fewer queries per call")
+    return sid_bits, delta_bits, bias
+
+
+def pairs_vote(ctx: "_ffi.Context", d_pairs, n: int, n_queries: int, layout, topn: int = 2):
+    """Rank the packed votes in a device buffer (overwritten) like align_matches."""
     res = {"sid": np.zeros((n_queries, topn), np.uint32), "delta": np.zeros((n_queries, topn), np.int32),
            "aligned": np.zeros((n_queries, topn), np.uint32), "dedup": np.zeros((n_queries, topn), np.uint32),
            "nres": np.zeros(n_queries, np.uint32)}
-    if n == 0:
-        cols = [None] * len(VOTE_COLS)
-    elif not device:
-        cols = [np.ascontiguousarray(c[:n], dt) for c, (_, dt) in zip(cols, VOTE_COLS)]
-    ctx.check(lib().shz_votes_merge(ctx.h, *[ptr(c) for c in cols], n, n_queries, topn, IN_DEVICE if device else 0,
-                                    ptr(res["sid"]), ptr(res["delta"]), ptr(res["aligned"]), ptr(res["dedup"]),
-                                    ptr(res["nres"])))
+    ctx.check(lib().shz_pairs_vote(ctx.h, ptr(d_pairs) if n else None, n, n_queries, *layout, topn, ptr(res["sid"]),
+                                   ptr(res["delta"]), ptr(res["aligned"]), ptr(res["dedup"]), ptr(res["nres"])))
     return res
 
 
@@ -100,15 +85,15 @@ class ShardedTable:
         self.tables = [_ffi.Table(ctx) for _ in range(1 if comm is not None else self.nshards)]
         self.bytes_received = 0
         self._stage = None       # staging table of insert_clips (shards on this GPU)
-        self._vcap = 0           # capacity of the device vote columns kept between match() calls
-        self._vcols = None
+        self._pbuf, self._pcap = None, 0    # device vote buffer kept between match() calls
+        self.last_votes = 0      # votes ranked by the last match()
 
     def close(self):
         for t in self.tables + ([self._stage] if self._stage is not None else []):
             t.close()
-        for b in self._vcols or []:
-            b.free()
-        self.tables, self._stage, self._vcols = [], None, None
+        if self._pbuf is not None:
+            self._pbuf.free()
+        self.tables, self._stage, self._pbuf, self._pcap = [], None, None, 0
 
     # -- build ---------------------------------------------------------------------------------
     def insert(self, key32, sid, off):
@@ -152,75 +137,81 @@ class ShardedTable:
         return sum(a for a, _ in r), sum(b for _, b in r)
 
     # -- query ---------------------------------------------------------------------------------
-    def match(self, key32, q_off, query_off, topn=2):
-        """Same result dict as ``Table.match`` on the union of all shards."""
-        qo = np.ascontiguousarray(query_off, np.uint64)
-        nq = len(qo) - 1
+    def _votes_into(self, k, o, qo, nq, layout, shard_ids):
+        """Run shz_match_pairs for the listed (shard index, table) pairs, appending into the device buffer.
+        Returns (n_votes, nhash, npairs) with the per-query counts summed over those shards."""
         ctx = self.ctx
-        if self.comm is None:
-            return self._match_local(key32, q_off, qo, nq, topn)
-        cols, n, nhash, npairs = match_votes(self.tables[0], key32, q_off, qo, device=True)
-        # counts first, then the records themselves
-        tot = C.c_uint64()
-        cap = None
-        gathered = None
-        while True:
-            if cap is None:
-                # a zero-capacity call returns the total through E_CAPACITY (or succeeds when there is nothing)
-                rc = lib().shz_votes_allgather(self.comm.h, n, *[ptr(c) for c in cols], None, None, None, None, None, 0,
-                                               C.byref(tot))
-                if rc == E_CAPACITY:
-                    cap = int(tot.value)
-                    continue
-                ctx.check(rc)
-                gathered, cap = [], 0
-                break
-            gathered = [ctx.alloc(max(cap, 1) * 4) for _ in VOTE_COLS]
-            ctx.check(lib().shz_votes_allgather(self.comm.h, n, *[ptr(c) for c in cols], *[ptr(g) for g in gathered], cap,
-                                                C.byref(tot)))
-            break
-        res = votes_merge(ctx, gathered, int(tot.value), nq, topn, device=True) if cap else votes_merge(ctx, [], 0, nq, topn)
-        for b in list(cols) + list(gathered):
-            b.free()
-        res["nhash"] = nhash
-        res["npairs"] = npairs  # this rank's share; sum over ranks = matches against the whole table
-        return res
+        if self._pbuf is None:
+            self._grow(max(1 << 16, 8 * len(k)))
+        dk = do = None
+        if len(shard_ids) > 1 and len(k):      # several passes over the same queries: upload them once
+            dk, do = ctx.alloc(k.nbytes), ctx.alloc(o.nbytes)
+            dk.upload(k)
+            do.upload(o)
+        try:
+            return self._votes_passes(dk if dk is not None else k, do if do is not None else o, dk is not None, qo, nq,
+                                      layout, shard_ids)
+        finally:
+            for b in (dk, do):
+                if b is not None:
+                    b.free()
 
-    def _match_local(self, key32, q_off, qo, nq, topn):
-        """Shards on this GPU: every shard appends its records to device columns, one merge reads them there."""
+    def _votes_passes(self, k, o, on_device, qo, nq, layout, shard_ids):
         ctx = self.ctx
-        k = np.ascontiguousarray(key32, np.uint32)
-        o = np.ascontiguousarray(q_off, np.uint32)
-        nhash = np.zeros(nq, np.uint32)
-        if self._vcap == 0:
-            self._grow_votes(max(1 << 16, 4 * len(k)))
         while True:
-            n, need, npairs = 0, 0, np.zeros(nq, np.uint64)
-            for t in self.tables:
-                cnt, np_s = C.c_uint64(), np.zeros(nq, np.uint64)
-                room = max(self._vcap - n, 0)
-                rc = lib().shz_match_votes(ctx.h, t.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, OUT_DEVICE,
-                                           *[ptr(b.ptr + 4 * n) for b in self._vcols], room, C.byref(cnt), ptr(nhash),
-                                           ptr(np_s))
+            n, need = 0, 0
+            nhash, npairs = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+            for i, t in shard_ids:
+                cnt, nh_s, np_s = C.c_uint64(), np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+                rc = lib().shz_match_pairs(ctx.h, t.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, IN_DEVICE if on_device else 0, i,
+                                           self.nshards, *layout,
+                                           ptr(self._pbuf.ptr + 8 * n), max(self._pcap - n, 0), C.byref(cnt), ptr(nh_s), ptr(np_s))
                 if rc not in (_ffi.OK, E_CAPACITY):
                     ctx.check(rc)
                 need += int(cnt.value)
                 if rc == _ffi.OK:
                     n += int(cnt.value)
+                nhash += nh_s
                 npairs += np_s
-            if need <= self._vcap:
-                break
-            self._grow_votes(need + need // 4)     # a shard did not fit: grow once and vote again
-        res = votes_merge(ctx, self._vcols, n, nq, topn, device=True)
-        res["nhash"] = nhash           # a property of the query alone
-        res["npairs"] = npairs         # matches add up over shards
-        return res
+            if need <= self._pcap:
+                return n, nhash, npairs
+            self._grow(need + need // 4)     # a shard did not fit: grow once and run the pass again
 
-    def _grow_votes(self, cap):
-        for b in self._vcols or []:
-            b.free()
-        self._vcols = [self.ctx.alloc(cap * 4) for _ in VOTE_COLS]
-        self._vcap = cap
+    def _grow(self, cap):
+        if self._pbuf is not None:
+            self._pbuf.free()
+        self._pbuf, self._pcap = self.ctx.alloc(cap * 8), cap
+
+    def match(self, key32, q_off, query_off, topn=2):
+        """Same result dict as ``Table.match`` on the union of all shards."""
+        ctx = self.ctx
+        k = np.ascontiguousarray(key32, np.uint32)
+        o = np.ascontiguousarray(q_off, np.uint32)
+        qo = np.ascontiguousarray(query_off, np.uint64)
+        nq = len(qo) - 1
+        mx = [table_maxima(t) for t in self.tables]     # after a shard exchange: maxima of the whole table
+        layout = vote_layout(max(a for a, _ in mx), max(b for _, b in mx), o, nq)
+        if self.comm is None:
+            n, nhash, npairs = self._votes_into(k, o, qo, nq, layout, list(enumerate(self.tables)))
+            res = pairs_vote(ctx, self._pbuf, n, nq, layout, topn)
+            self.last_votes = n
+        else:
+            n, nhash, npairs = self._votes_into(k, o, qo, nq, layout, [(self.comm.rank, self.tables[0])])
+            tot = C.c_uint64()
+            # a zero-capacity call returns the total through E_CAPACITY (or succeeds when there is nothing at all)
+            rc = lib().shz_pairs_allgather(self.comm.h, n, ptr(self._pbuf), None, 0, C.byref(tot))
+            if rc != E_CAPACITY:
+                ctx.check(rc)
+            total = int(tot.value)
+            gathered = ctx.alloc(max(total, 1) * 8)
+            if total:
+                ctx.check(lib().shz_pairs_allgather(self.comm.h, n, ptr(self._pbuf), ptr(gathered), total, C.byref(tot)))
+            res = pairs_vote(ctx, gathered, total, nq, layout, topn)
+            gathered.free()
+            self.last_votes = total
+            # nhash / npairs: this rank's share; their sum over the ranks is the unsharded table's value
+        res["nhash"], res["npairs"] = nhash, npairs
+        return res
 
     # -- the rest of Table's surface (shards on this GPU only) ------------------------------------
     def _local_only(self, what):
@@ -269,5 +260,7 @@ class ShardedTable:
         return sum(t.song_rows(sid) for t in self.tables)
 
     def match_stats(self):
-        """Counters of the LAST shard's vote pass (rows scanned / pairs / distinct keys)."""
-        return self.tables[-1].match_stats()
+        """Counters of the last match(): votes ranked; rows scanned / distinct keys of the last shard's pass."""
+        st = self.tables[-1].match_stats()
+        st["pairs"] = self.last_votes
+        return st

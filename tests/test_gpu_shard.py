@@ -1,7 +1,7 @@
 """GPU: a key-sharded table must answer exactly like the unsharded one.
 
-The shards vote separately (shz_match_votes), the records are concatenated / all-gathered and merged
-(shz_votes_merge).  Parity bar: every output array of Table.match, bit for bit, for several shard counts,
+Every shard emits the packed votes of its rows (shz_match_pairs); they are concatenated / all-gathered and ranked
+once (shz_pairs_vote).  Parity bar: every output array of Table.match, bit for bit, for several shard counts,
 including tie cases (equal counts for two songs / two offset differences) and queries without matches."""
 import numpy as np
 import pytest
@@ -79,40 +79,62 @@ def test_sharded_fingerprint_db_and_ties():
     sh.close()
 
 
-def test_votes_capacity_and_merge_inputs():
+def test_pairs_capacity_layout_and_vote_inputs():
     import ctypes as C
     import shazam_amd as S
     from shazam_amd import _ffi
-    from shazam_amd.shard import match_votes, votes_merge
+    from shazam_amd.shard import pairs_vote, table_maxima, vote_layout
     ctx = S.get_context(0)
     rng = np.random.default_rng(5)
     k, s, o = _rows(rng, 20000)
     t = S.Table(ctx)
     t.insert(k, s, o)
     t.finalize()
+    assert table_maxima(t) == (int(s.max()), int(o.max()))
     qk, qo, qoff = _queries(rng, k, 8)
-    cols, n, nhash, npairs = match_votes(t, qk, qo, qoff)
-    assert n > 0 and all(len(c) == n for c in cols)
-    assert int(cols[3].sum()) == int(npairs.sum())           # every match is in exactly one record
-    assert np.all(cols[4] <= cols[3])
-    # too small a capacity reports the size needed and writes nothing past it
-    cnt = C.c_uint64()
-    small = [np.full(4, 0xAB, dt) for dt in (np.uint32, np.uint32, np.int32, np.uint32, np.uint32)]
-    rc = _ffi.lib().shz_match_votes(ctx.h, t.h, _ffi.ptr(qk), _ffi.ptr(qo), qoff.ctypes.data_as(_ffi.u64p), len(qoff) - 1, 0,
-                                    *[_ffi.ptr(c) for c in small], 4, C.byref(cnt), None, None)
-    assert rc == _ffi.E_CAPACITY and cnt.value == n
-    # merging the records of one table reproduces match(); record order does not matter
+    nq = len(qoff) - 1
     ref = t.match(qk, qo, qoff, 2)
-    perm = rng.permutation(n)
-    got = votes_merge(ctx, [c[perm] for c in cols], n, len(qoff) - 1, 2)
+    lay = vote_layout(*table_maxima(t), qo, nq)
+
+    def pairs(cap, layout=lay, shard=0, nshards=1):
+        buf, cnt = ctx.alloc(max(cap, 1) * 8), C.c_uint64()
+        nh, npr = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+        rc = _ffi.lib().shz_match_pairs(ctx.h, t.h, _ffi.ptr(qk), _ffi.ptr(qo), qoff.ctypes.data_as(_ffi.u64p), nq, 0, shard,
+                                        nshards, *layout, _ffi.ptr(buf), cap, C.byref(cnt), _ffi.ptr(nh), _ffi.ptr(npr))
+        return rc, buf, int(cnt.value), nh, npr
+
+    total = int(ref["npairs"].sum())
+    rc, buf, n, nh, npr = pairs(total)
+    assert rc == _ffi.OK and n == total and np.array_equal(nh, ref["nhash"]) and np.array_equal(npr, ref["npairs"])
+    # too small a capacity reports the size needed
+    rc2, small, n2, _, _ = pairs(7)
+    assert rc2 == _ffi.E_CAPACITY and n2 == total
+    small.free()
+    # the votes of one table, in any order, rank to exactly match()
+    v = buf.download(np.uint64, n)
+    buf.upload(v[rng.permutation(n)])
+    got = pairs_vote(ctx, buf, n, nq, lay, 2)
     for f in ("sid", "delta", "aligned", "dedup", "nres"):
         assert np.array_equal(ref[f], got[f]), f
-    # no records at all
-    empty = votes_merge(ctx, [], 0, 3, 2)
+    buf.free()
+    # a layout that cannot hold this table's song ids or these queries' offsets is refused, not truncated
+    for bad in ((lay[0] - 1, lay[1], lay[2]), (lay[0], lay[1], max(lay[2] - 1, 0)) if lay[2] else (lay[0], 1, 0)):
+        rcb, b2, _, _, _ = pairs(total, layout=bad)
+        assert rcb == _ffi.E_INVALID
+        b2.free()
+    # a shard index outside [0, nshards) too
+    rcb, b2, _, _, _ = pairs(total, shard=2, nshards=2)
+    assert rcb == _ffi.E_INVALID
+    b2.free()
+    # shards split the query hashes: the per-query counts of the parts add up to the whole
+    parts = [pairs(total, shard=i, nshards=3) for i in range(3)]
+    assert all(p[0] == _ffi.OK for p in parts)
+    assert np.array_equal(sum(p[3] for p in parts), ref["nhash"])
+    for p in parts:
+        p[1].free()
+    # no votes at all
+    empty = pairs_vote(ctx, None, 0, 3, lay, 2)
     assert not empty["nres"].any()
-    # a query index outside [0, n_queries) is rejected
-    with pytest.raises(_ffi.ShzError):
-        votes_merge(ctx, cols, n, 2, 2)
     t.close()
 
 
