@@ -87,6 +87,15 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
         if dist:
             dist.barrier()
 
+    # the measured streaming bandwidth of this GPU beside the vendor peak the fraction is quoted on
+    try:
+        bw = {m: ctx.membw(i, 2 << 30, 5) for i, m in enumerate(("copy", "read", "write"))}
+        rf = out["roofline"]
+        rf["measured_stream_GBs"] = bw
+        rf["frac_of_measured_copy"] = rf["achieved"] / bw["copy"] if bw["copy"] > 0 else None
+    except Exception as e:  # noqa: BLE001
+        out["roofline"]["measured_stream_error"] = repr(e)
+
     from shazam_amd import Table
     tbl = Table(ctx)
     comm = None

@@ -84,6 +84,11 @@ int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t
 int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
                       int32_t tone_amp, int32_t noise_amp, uint64_t start_sample, int16_t* dev_out);
 
+/* HBM bandwidth probe (the measured ceiling beside the vendor peak): mode 0 copy (bytes read +
+ * bytes written are counted), 1 read only, 2 write only; two scratch buffers of `bytes` each are allocated and
+ * freed inside; gb_per_s = bytes moved / hipEvent time over `iters` launches (16 B per lane, grid-stride). */
+int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s);
+
 /* Query preparation (bench / tests): exact sum of squares of each clip (device PCM, clip-major, equal
  * lengths) to HOST, and out = clip(rint(sig + scale[c] * noise)) on the device: the digital form of
  * get_noise_from_sound + sf.write (recognizer_test.py:426-435, 557); twin: oracle/synth.mix_query. */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "shz_synth_pcm": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, vp]),
     "shz_sumsq_i16": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint64, u64p]),
     "shz_mix_i16": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, f64p, vp]),
+    "shz_membw": (C.c_int32, [vp, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -187,6 +188,12 @@ class Context:
 
     def sync(self):
         self.check(lib().shz_sync(self.h))
+
+    def membw(self, mode: int = 0, nbytes: int = 4 << 30, iters: int = 5) -> float:
+        """Measured HBM GB/s of a 16-B/lane stream: mode 0 copy (read + write), 1 read, 2 write."""
+        g = C.c_float()
+        self.check(lib().shz_membw(self.h, int(mode), int(nbytes), int(iters), C.byref(g)))
+        return float(g.value)
 
     def set_workspace_limit(self, nbytes):
         self.check(lib().shz_set_workspace_limit(self.h, int(nbytes)))

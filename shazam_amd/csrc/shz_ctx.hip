@@ -383,3 +383,58 @@ extern "C" int32_t shz_mix_i16(shz_ctx* ctx, const int16_t* dev_sig, const int16
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------- HBM bandwidth probe
+// "confirm on the box with a stream-copy microbench and use the measured copy bandwidth as the
+// practical ceiling".  16 bytes per lane, grid-stride, buffers far larger than L2 + Infinity Cache.
+__global__ __launch_bounds__(256) void membw_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16,
+                                                    int mode, uint32_t* __restrict__ sink) {
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (mode == 2) {
+      dst[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
+    } else {
+      const uint4 v = src[i];
+      if (mode == 0) dst[i] = v;
+      else { acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+    }
+  }
+  if (mode == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = 1;  // keeps the loads alive
+}
+
+extern "C" int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s) {
+  if (!ctx || !gb_per_s) return SHZ_E_INVALID;
+  if (mode < 0 || mode > 2 || bytes < (1ull << 20) || iters < 1) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_membw: mode 0..2, >= 1 MiB, >= 1 iteration");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t n16 = bytes / 16;
+  void *a = nullptr, *b = nullptr, *sink = nullptr;
+  if (hipMalloc(&a, n16 * 16) != hipSuccess || hipMalloc(&b, n16 * 16) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) {
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_membw: hipMalloc(2 x %llu) failed", (unsigned long long)(n16 * 16));
+  }
+  (void)hipMemsetAsync(a, 0x5A, n16 * 16, ctx->stream);
+  (void)hipMemsetAsync(b, 0, n16 * 16, ctx->stream);
+  const unsigned grid = (unsigned)ctx->prop.multiProcessorCount * 16;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(membw_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16, mode, (uint32_t*)sink);  // warm-up
+  (void)hipEventRecord(e0, ctx->stream);
+  for (uint32_t it = 0; it < iters; ++it)
+    hipLaunchKernelGGL(membw_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16, mode, (uint32_t*)sink);
+  (void)hipEventRecord(e1, ctx->stream);
+  hipError_t err = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipFree(sink);
+  SHZ_HIP(ctx, err);
+  const double moved = (double)(n16 * 16) * iters * (mode == 0 ? 2.0 : 1.0);  // copy = one read + one write
+  *gb_per_s = ms > 0.f ? (float)(moved / (ms * 1e-3) / 1e9) : 0.f;
+  return SHZ_OK;
+}
