@@ -269,7 +269,7 @@ __device__ __forceinline__ double pk_lds_ld(uint32_t a) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x) : "v"(a), "n"(OFF) : "memory");
   return x;
 }
-// row ROW of the group: x[0..9] = pr2[ROW][j + 2d], x[10] = raw[ROW][j + 20]   (rows are 256 doubles apart)
+// row ROW of the group: x[0..9] = pr2[ROW][c + 2d], x[10] = raw[ROW][c + 20], c = output column (rows are 256 doubles apart)
 template <int ROW>
 __device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, uint32_t a_raw, double (&x)[11]) {
   x[0] = pk_lds_ld<ROW * 2048 + 0>(a_pr2);
@@ -292,6 +292,12 @@ __device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, uint32_t a_raw, dou
                  "+v"(x[8]), "+v"(x[9]), "+v"(x[10])                                                                \
                :                                                                                                   \
                : "memory")
+// value of the next lane (lane + 1) of the wave; lane 63 gets an unspecified value
+__device__ __forceinline__ double pk_wave_shl1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double pk_row_max(const double (&x)[11]) {
   const double a = fmax(fmax(x[0], x[1]), fmax(x[2], x[3]));
   const double b = fmax(fmax(x[4], x[5]), fmax(x[6], x[7]));
@@ -310,20 +316,21 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   const uint32_t slab = blockIdx.x;
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const double NEG = -__builtin_inf();
-  // thread -> column: outputs first so that wave w's ballot covers slab bins [64w, 64w+63]
-  int li;  // index in the LDS row = column - (slab*PK_SW - 10)
-  if (j < PK_SW) li = j + 10;
-  else if (j < PK_SW + 10) li = j - PK_SW;
-  else li = j;  // j in [238,248) -> right halo; j >= 248 idle
+  // thread -> column of the LDS row: wave w, lane l holds column li = 63 w + l, so lane 63 repeats lane 0 of the next
+  // wave.  With that one column of overlap every lane below 63 finds its right neighbour in its own wave: the pair
+  // maxima come from a DPP wave shift instead of a second trip through LDS (one barrier and seven LDS reads less
+  // per group).  Lane 63 loads and stores the raw value like its twin but produces no pair maximum and no output.
+  const int li = 63 * wave + lane;  // = column - (slab*PK_SW - 10); li >= PK_COLS (wave 3, lanes 59..63) is idle
   const long long col = (long long)slab * PK_SW - 10 + li;
-  const bool loads = j < PK_COLS && col >= 0 && col < (long long)n_bins;
-  const bool is_out = j < PK_SW && col < (long long)n_bins;
+  const bool loads = li < PK_COLS && col >= 0 && col < (long long)n_bins;
+  const bool reads = li >= 10 && li < PK_SW + 10 && lane < 63;  // owns output column li - 10
+  const bool is_out = reads && col < (long long)n_bins;
   const int lo = (int)sg.t0 - 10 > 0 ? (int)sg.t0 - 10 : 0;
   const int hi = (int)(sg.t1 + 10 < sg.nframes ? sg.t1 + 10 : sg.nframes);
   const int end = (int)sg.t1 + 10;  // last iteration decides frame t1-1
   const double* src = A + (uint64_t)sg.gframe0 * row_stride + (loads ? col : 0);
-  const uint32_t a_pr2 = (uint32_t)(uintptr_t)(pk_lds_cd*)&pr2[0][j < PK_SW ? j : 0];
-  const uint32_t a_raw = (uint32_t)(uintptr_t)(pk_lds_cd*)&raw[0][j < PK_SW ? j + 20 : 0];
+  const uint32_t a_pr2 = (uint32_t)(uintptr_t)(pk_lds_cd*)&pr2[0][reads ? li - 10 : 0];   // window = columns li-10 .. li+10
+  const uint32_t a_raw = (uint32_t)(uintptr_t)(pk_lds_cd*)&raw[0][reads ? li + 10 : 0];
 
   double prevS[21], cur[21], pre[PK_PF];
   uint32_t fc = 0, fp = 0, sp = 0;  // row-max flags of the current / previous block, suffix-max flags
@@ -348,14 +355,13 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
         pre[i] = (loads && tn < hi) ? src[(uint64_t)tn * row_stride] : NEG;
       }
       __syncthreads();  // every wave is done reading the previous group's rows
-      if (j < PK_COLS) {
+      if (li < PK_COLS) {
 #pragma unroll
-        for (int i = 0; i < PK_PF; ++i) raw[i][li] = v[i];
-      }
-      __syncthreads();
-      if (j < PK_COLS) {
-#pragma unroll
-        for (int i = 0; i < PK_PF; ++i) pr2[i][li] = fmax(v[i], (li + 1 < PK_COLS) ? raw[i][li + 1] : NEG);
+        for (int i = 0; i < PK_PF; ++i) {
+          raw[i][li] = v[i];
+          const double nb = pk_wave_shl1(v[i]);        // column li + 1 (idle lanes hold -inf)
+          if (lane < 63) pr2[i][li] = fmax(v[i], nb);
+        }
       }
       __syncthreads();
       // Row maxima over columns j .. j+20 = pairs (j, j+1) .. (j+18, j+19) and column j+20.  The eleven reads of a
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
       // flight: the reads of row i+1 are issued before row i is reduced.
 #pragma unroll
       for (int i = 0; i < PK_PF; ++i) m1[i] = NEG;
-      if (j < PK_SW) {
+      if (reads) {
         double xa[11], xb[11];
         pk_row_reads<0>(a_pr2, a_raw, xa);
         pk_row_reads<1>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[0] = pk_row_max(xa);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __rest
   while (m) {
     const int b = __ffsll((long long)m) - 1;
     m &= m - 1;
-    peak_f[o] = (uint16_t)(slab * PK_SW + wv * 64 + b);
+    peak_f[o] = (uint16_t)(slab * PK_SW + wv * 63 + b - 10);  // wave wv, lane b holds slab column 63 wv + b - 10
     peak_t[o] = t;
     ++o;
   }
