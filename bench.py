@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS = 44100
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured stream rates of the box
+#                        (copy ~5.0, read ~6.2, write ~4.0 TB/s) go into roofline.measured_stream_GBs
 STFT_BYTES_PER_FRAME = 4096 + 2049 * 8   # new PCM read + dB row written (staged kernel I/O)
 COMPULSORY_BYTES_PER_FRAME = 4096 + 147  # PCM in + ~18.4 hashes x 8 B out
 
