@@ -54,6 +54,21 @@ static int bits_for(uint64_t v) {
   return b ? b : 1;
 }
 
+// device allocations of one call: freed when the call leaves early (SHZ_TRY / SHZ_FAIL return), handed over with take()
+struct dev_cols {
+  uint32_t* p[3] = {nullptr, nullptr, nullptr};
+  ~dev_cols() {
+    for (uint32_t* q : p)
+      if (q) (void)hipFree(q);
+  }
+  bool alloc(uint64_t rows) {
+    for (auto& q : p)
+      if (hipMalloc(&q, std::max<uint64_t>(rows, 1) * 4) != hipSuccess) return false;
+    return true;
+  }
+  uint32_t* take(int i) { uint32_t* q = p[i]; p[i] = nullptr; return q; }
+};
+
 // ---------------------------------------------------------------------------------------- kernels
 __global__ void tbl_expand_clips_kernel(const uint32_t* __restrict__ key32, const uint32_t* __restrict__ t1,
                                         const uint64_t* __restrict__ hash_off, uint32_t n_clips, uint32_t sid0,
@@ -667,17 +682,16 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
   if (bytes_recv) *bytes_recv = (total - mine) * 12;
   if (total == 0) return shz_table_finalize(t);
   // 2) per column: every rank's block lands at its displacement in the gathered column
-  uint32_t* g[3];
-  for (int i = 0; i < 3; ++i)
-    if (hipMalloc(&g[i], total * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
+  dev_cols gc;
+  if (!gc.alloc(total)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
   const uint32_t* mine_cols[3] = {t->skey, t->ssid, t->soff};
-  for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, mine_cols[i], g[i], bytes.data(), displ.data()));
+  for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, mine_cols[i], gc.p[i], bytes.data(), displ.data()));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // 3) the gathered columns become the staged rows; finalize sorts + dedups them with the existing table
   void* olds[] = {t->skey, t->ssid, t->soff};
   for (void* p : olds)
     if (p) SHZ_HIP(ctx, hipFree(p));
-  t->skey = g[0]; t->ssid = g[1]; t->soff = g[2];
+  t->skey = gc.take(0); t->ssid = gc.take(1); t->soff = gc.take(2);
   t->ns = t->scap = total;
   return shz_table_finalize(t);
 }
@@ -1254,14 +1268,13 @@ extern "C" int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t n
   if (nshards == 0 || shard >= nshards) SHZ_FAIL(ctx, SHZ_E_INVALID, "keep_shard: shard %u of %u", shard, nshards);
   if (t->ns == 0 || nshards == 1) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  uint32_t* g[3];
-  for (int i = 0; i < 3; ++i)
-    if (hipMalloc(&g[i], t->ns * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "keep_shard: hipMalloc(%llu) failed", (unsigned long long)(t->ns * 4));
+  dev_cols g;
+  if (!g.alloc(t->ns)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "keep_shard: hipMalloc(%llu) failed", (unsigned long long)(t->ns * 4));
   uint64_t kept = 0;
-  SHZ_TRY(stage_select_shard(t, nshards, shard, g[0], g[1], g[2], &kept));
+  SHZ_TRY(stage_select_shard(t, nshards, shard, g.p[0], g.p[1], g.p[2], &kept));
   void* olds[] = {t->skey, t->ssid, t->soff};
   for (void* p : olds) SHZ_HIP(ctx, hipFree(p));
-  t->skey = g[0]; t->ssid = g[1]; t->soff = g[2];
+  t->skey = g.take(0); t->ssid = g.take(1); t->soff = g.take(2);
   t->scap = t->ns;
   t->ns = kept;
   return SHZ_OK;
@@ -1274,10 +1287,10 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   int rank, nranks;
   shz_comm_info(c, &rank, &nranks);
   // 1) partition the staged rows by destination: the send columns hold the blocks for rank 0, 1, ... back to back
-  uint32_t* snd[3] = {nullptr, nullptr, nullptr};
   const uint64_t ns = t->ns;
-  for (int i = 0; i < 3; ++i)
-    if (hipMalloc(&snd[i], std::max<uint64_t>(ns, 1) * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(ns * 4));
+  dev_cols sndc, rcvc;
+  if (!sndc.alloc(ns)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(ns * 4));
+  uint32_t** snd = sndc.p;
   std::vector<uint64_t> scnt(nranks, 0), sdis(nranks, 0);
   uint64_t pos = 0;
   for (int d = 0; d < nranks && ns; ++d) {
@@ -1304,18 +1317,17 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   }
   if (bytes_recv) *bytes_recv = (total - rcnt[rank]) * 12;
   // 3) one grouped all-to-all per column
-  uint32_t* rcv[3] = {nullptr, nullptr, nullptr};
-  for (int i = 0; i < 3; ++i)
-    if (hipMalloc(&rcv[i], std::max<uint64_t>(total, 1) * 4) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
+  if (!rcvc.alloc(total)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
+  uint32_t** rcv = rcvc.p;
   std::vector<uint64_t> sb(nranks), sd(nranks), rb(nranks), rd(nranks);
   for (int r = 0; r < nranks; ++r) { sb[r] = scnt[r] * 4; sd[r] = sdis[r] * 4; rb[r] = rcnt[r] * 4; rd[r] = rdis[r] * 4; }
   for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_alltoallv_bytes(c, snd[i], sb.data(), sd.data(), rcv[i], rb.data(), rd.data()));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // 4) the received rows are this rank's shard: they replace the staged rows
-  void* olds[] = {t->skey, t->ssid, t->soff, snd[0], snd[1], snd[2]};
+  void* olds[] = {t->skey, t->ssid, t->soff};
   for (void* p : olds)
     if (p) SHZ_HIP(ctx, hipFree(p));
-  t->skey = rcv[0]; t->ssid = rcv[1]; t->soff = rcv[2];
+  t->skey = rcvc.take(0); t->ssid = rcvc.take(1); t->soff = rcvc.take(2);  // the send columns go with sndc
   t->ns = total;
   t->scap = std::max<uint64_t>(total, 1);
   SHZ_TRY(shz_table_finalize(t));
