@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--noise-amp", type=int, default=1500)
     ap.add_argument("--topn", type=int, default=2)
     ap.add_argument("--finalize-every", type=int, default=0, help="songs between intermediate finalize calls (0 = once at the end)")
+    ap.add_argument("--mixed-ingest", type=int, default=0, help="songs ingested (fingerprint + insert + finalize) before every "
+                    "query batch: the mixed ingest + query stream of BASELINE configs[4]; 0 = queries only")
     ap.add_argument("--shards", type=int, default=1, help="partition the table by key into this many shards on the GPU "
                     "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
     a = ap.parse_args()
@@ -91,8 +93,27 @@ def main():
     starts = rng.integers(0, n_samples - qn, nq)
     lat, correct, tot_pairs, tot_rows, tot_hash = [], 0, 0, 0, 0
     t_qfp = 0.0
+    mixed = {"songs": 0, "seconds": 0.0, "finalize_s": 0.0, "batches": 0}
+    n_mix = min(a.mixed_ingest, a.chunk)
+    mix_pcm = ctx.alloc(n_mix * n_samples * 2) if n_mix else None
+    t_stream0 = time.perf_counter()
     for b0 in range(0, nq, a.match_batch):
         nb = min(a.match_batch, nq - b0)
+        if n_mix:   # new songs arrive between the query batches; their ids continue after the base corpus
+            c0 = a.songs + mixed["songs"]
+            ctx.synth_pcm(4321, c0, n_mix, n_samples, a.tone_amp, a.noise_amp, out=mix_pcm)
+            ctx.sync()
+            t0 = time.perf_counter()
+            _, _, ho_m, _ = ctx.fingerprint_batch(mix_pcm, np.arange(n_mix + 1, dtype=np.uint64) * n_samples, fs=FS,
+                                                  pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
+            tbl.insert_clips(kbuf, tbuf, ho_m, sid0=1 + c0, device=True)
+            t1_ = time.perf_counter()
+            tbl.finalize()
+            ctx.sync()
+            mixed["finalize_s"] += time.perf_counter() - t1_
+            mixed["seconds"] += time.perf_counter() - t0
+            mixed["songs"] += n_mix
+            mixed["batches"] += 1
         sig, noi = ctx.alloc(nb * qn * 2), ctx.alloc(nb * qn * 2)
         for i in range(nb):
             ctx.check(_ffi.lib().shz_synth_pcm(ctx.h, 4321, int(tids[b0 + i]), 1, qn, a.tone_amp, a.noise_amp,
@@ -131,6 +152,16 @@ def main():
            "build": {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
                      "rows_inserted": int(n_rows_in), "songs_per_s": a.songs / t_build,
                      "audio_s_per_s": a.songs * a.seconds / t_build}}
+    if n_mix:
+        t_stream = time.perf_counter() - t_stream0   # includes query synthesis / mixing on the device
+        out["mixed"] = {"ingest_batch_songs": n_mix, "batches": mixed["batches"], "songs_ingested": mixed["songs"],
+                        "rows_after": int(tbl.rows()[0]), "ingest_s_per_batch": mixed["seconds"] / max(mixed["batches"], 1),
+                        "finalize_s_per_batch": mixed["finalize_s"] / max(mixed["batches"], 1),
+                        "stream_seconds": t_stream, "sustained_ingest_songs_per_s": mixed["songs"] / t_stream,
+                        "sustained_qps": nq / t_stream,
+                        "note": "one GPU alternating ingest batches and query batches; replicas multiply the QPS, the "
+                                "ingest is repeated on every replica"}
+        mix_pcm.free()
     print(json.dumps(out))
 
 
