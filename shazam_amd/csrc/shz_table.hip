@@ -30,6 +30,7 @@ struct shz_table {
   uint64_t seg_limit = 1ull << 31;     // rows per segment (bounds the sort scratch: 16 B/row)
   uint32_t *key = nullptr, *sid = nullptr, *off = nullptr;   // active segment
   uint64_t n = 0;
+  uint64_t cap = 0, bcap = 0;  // rows the active columns / entries the bucket array can hold (reused across finalize calls)
   uint32_t *skey = nullptr, *ssid = nullptr, *soff = nullptr;
   uint64_t ns = 0, scap = 0;
   uint32_t* bucket = nullptr;
@@ -318,6 +319,29 @@ extern "C" int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, c
   return SHZ_OK;
 }
 
+// merge of two sorted u64 runs (merge path): thread t produces outputs [t*PT, (t+1)*PT).  Ties take the element of
+// `a` first.  Used by finalize when a sorted active segment absorbs a (much smaller) sorted batch of new rows: one
+// pass over the data instead of a radix sort of everything.
+#define MERGE_PT 8
+__global__ __launch_bounds__(256) void tbl_merge_kernel(const uint64_t* __restrict__ a, uint64_t na,
+                                                        const uint64_t* __restrict__ b, uint64_t nb,
+                                                        uint64_t* __restrict__ out) {
+  const uint64_t total = na + nb;
+  const uint64_t diag = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MERGE_PT;
+  if (diag >= total) return;
+  uint64_t lo = diag > nb ? diag - nb : 0, hi = diag < na ? diag : na;  // elements taken from a before this diagonal
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (a[mid] <= b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  uint64_t i = lo, j = diag - lo;
+  const uint64_t end = diag + MERGE_PT < total ? diag + MERGE_PT : total;
+  for (uint64_t o = diag; o < end; ++o) {
+    const bool take_a = j >= nb || (i < na && a[i] <= b[j]);
+    out[o] = take_a ? a[i++] : b[j++];
+  }
+}
+
 // merge `ns` staged rows (columns skey/ssid/soff, not freed here) into the active segment
 static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_t* ssid, const uint32_t* soff, uint64_t ns) {
   shz_ctx* ctx = t->ctx;
@@ -358,8 +382,20 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
       hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((ns + 255) / 256, 8192)), dim3(256), 0,
                          ctx->stream, skey, ssid, soff, ns, t->n, sb, ob, ka);
     SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_sort_u64(ctx, ka, kb, nullptr, nullptr, 0, total, 0, 32 + sb + ob, &sel));
-    if (sel) std::swap(ka, kb);
+    if (t->n && ns) {
+      // the active rows are already in order (the packing is monotone in (key, sid, off)): sort only the new rows and
+      // merge the two runs -- one pass over the segment instead of a radix sort of all of it
+      SHZ_TRY(shz_sort_u64(ctx, ka + t->n, kb + t->n, nullptr, nullptr, 0, ns, 0, 32 + sb + ob, &sel));
+      if (sel) SHZ_HIP(ctx, hipMemcpyAsync(ka + t->n, kb + t->n, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      const uint64_t nthreads = (total + MERGE_PT - 1) / MERGE_PT;
+      hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const uint64_t*)ka, t->n, (const uint64_t*)(ka + t->n), ns, kb);
+      SHZ_HIP(ctx, hipGetLastError());
+      std::swap(ka, kb);
+    } else {
+      SHZ_TRY(shz_sort_u64(ctx, ka, kb, nullptr, nullptr, 0, total, 0, 32 + sb + ob, &sel));
+      if (sel) std::swap(ka, kb);
+    }
     hipLaunchKernelGGL(tbl_uniq1_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint64_t*)ka, total, (uint32_t*)fl);
   } else {
@@ -394,18 +430,23 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   uint64_t nu = 0;
   SHZ_HIP(ctx, hipMemcpyAsync(&nu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // the old columns are dead once composed: free them before allocating the new ones (peak memory)
-  {
-    void* olds[] = {t->key, t->sid, t->off, t->bucket};
+  // The old columns are dead once composed.  If they can hold the merged rows they are written in place (no
+  // hipFree / hipMalloc of gigabytes per finalize: that, not the kernels, dominated incremental ingest); otherwise they
+  // are freed before the new ones are allocated (peak memory), with 1/8 headroom for the next batches.
+  t->n = 0;
+  if (nu > t->cap) {
+    void* olds[] = {t->key, t->sid, t->off};
     for (void* p : olds)
       if (p) SHZ_HIP(ctx, hipFree(p));
-    t->key = t->sid = t->off = t->bucket = nullptr;
-    t->n = 0;
+    t->key = t->sid = t->off = nullptr;
+    t->cap = 0;
+    const uint64_t want = std::min<uint64_t>(nu + nu / 8 + 1024, std::max<uint64_t>(nu, t->seg_limit) + 1024);
+    if (hipMalloc(&t->key, want * 4) != hipSuccess || hipMalloc(&t->sid, want * 4) != hipSuccess ||
+        hipMalloc(&t->off, want * 4) != hipSuccess)
+      SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)want);
+    t->cap = want;
   }
-  uint32_t *nk, *nsid, *noff;
-  if (hipMalloc(&nk, nu * 4 + 4) != hipSuccess || hipMalloc(&nsid, nu * 4 + 4) != hipSuccess ||
-      hipMalloc(&noff, nu * 4 + 4) != hipSuccess)
-    SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)nu);
+  uint32_t *nk = t->key, *nsid = t->sid, *noff = t->off;
   if (one_key)
     hipLaunchKernelGGL(tbl_compact1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint64_t*)ka, (const uint32_t*)fl, (const uint32_t*)ps, total, sb, ob, nk, nsid, noff);
@@ -417,11 +458,15 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   uint32_t last_key = 0;
   SHZ_HIP(ctx, hipMemcpyAsync(&last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  t->key = nk; t->sid = nsid; t->off = noff;
   t->n = nu;
   t->nbuckets = (uint64_t)(last_key >> 8) + 1;
-  t->bucket = nullptr;
-  SHZ_HIP(ctx, hipMalloc(&t->bucket, (t->nbuckets + 1) * 4));
+  if (t->nbuckets + 1 > t->bcap) {
+    if (t->bucket) SHZ_HIP(ctx, hipFree(t->bucket));
+    t->bucket = nullptr;
+    t->bcap = 0;
+    SHZ_HIP(ctx, hipMalloc(&t->bucket, (t->nbuckets + 1) * 4));
+    t->bcap = t->nbuckets + 1;
+  }
   hipLaunchKernelGGL(tbl_bucket_kernel, dim3((unsigned)((t->nbuckets + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                      (const uint32_t*)t->key, (uint32_t)t->n, t->nbuckets, t->bucket);
   SHZ_HIP(ctx, hipGetLastError());
@@ -435,6 +480,7 @@ static void freeze_active(shz_table* t) {
   t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
   t->key = t->sid = t->off = t->bucket = nullptr;
   t->n = t->nbuckets = 0;
+  t->cap = t->bcap = 0;
 }
 
 extern "C" int32_t shz_table_finalize(shz_table* t) {
