@@ -319,27 +319,51 @@ extern "C" int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, c
   return SHZ_OK;
 }
 
-// merge of two sorted u64 runs (merge path): thread t produces outputs [t*PT, (t+1)*PT).  Ties take the element of
-// `a` first.  Used by finalize when a sorted active segment absorbs a (much smaller) sorted batch of new rows: one
-// pass over the data instead of a radix sort of everything.
+// merge of two sorted u64 runs (merge path).  A workgroup produces a tile of MERGE_TILE outputs: the tile's share of
+// `a` and `b` (found by one binary search per tile edge) is staged in LDS with coalesced loads, every thread merges
+// MERGE_PT outputs there, and the tile leaves with coalesced stores.  Ties take the element of `a` first.  Used by
+// finalize when a sorted active segment absorbs a (much smaller) sorted batch of new rows: one pass over the data
+// instead of a radix sort of everything.
 #define MERGE_PT 8
-__global__ __launch_bounds__(256) void tbl_merge_kernel(const uint64_t* __restrict__ a, uint64_t na,
-                                                        const uint64_t* __restrict__ b, uint64_t nb,
-                                                        uint64_t* __restrict__ out) {
-  const uint64_t total = na + nb;
-  const uint64_t diag = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MERGE_PT;
-  if (diag >= total) return;
-  uint64_t lo = diag > nb ? diag - nb : 0, hi = diag < na ? diag : na;  // elements taken from a before this diagonal
+#define MERGE_TILE (256 * MERGE_PT)
+__device__ __forceinline__ uint64_t merge_split(const uint64_t* __restrict__ a, uint64_t na, const uint64_t* __restrict__ b,
+                                                uint64_t nb, uint64_t diag) {  // elements of a among the first diag outputs
+  uint64_t lo = diag > nb ? diag - nb : 0, hi = diag < na ? diag : na;
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
     if (a[mid] <= b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
   }
-  uint64_t i = lo, j = diag - lo;
-  const uint64_t end = diag + MERGE_PT < total ? diag + MERGE_PT : total;
-  for (uint64_t o = diag; o < end; ++o) {
-    const bool take_a = j >= nb || (i < na && a[i] <= b[j]);
-    out[o] = take_a ? a[i++] : b[j++];
+  return lo;
+}
+__global__ __launch_bounds__(256) void tbl_merge_kernel(const uint64_t* __restrict__ a, uint64_t na,
+                                                        const uint64_t* __restrict__ b, uint64_t nb,
+                                                        uint64_t* __restrict__ out) {
+  __shared__ uint64_t sin[MERGE_TILE];   // the tile's elements of a, then those of b
+  __shared__ uint64_t sout[MERGE_TILE];
+  __shared__ uint64_t edge[2];
+  const uint64_t total = na + nb;
+  const uint64_t d0 = (uint64_t)blockIdx.x * MERGE_TILE;
+  if (d0 >= total) return;
+  const uint64_t d1 = d0 + MERGE_TILE < total ? d0 + MERGE_TILE : total;
+  if (threadIdx.x < 2) edge[threadIdx.x] = merge_split(a, na, b, nb, threadIdx.x ? d1 : d0);
+  __syncthreads();
+  const uint64_t a0 = edge[0], a1 = edge[1], b0 = d0 - a0, b1 = d1 - a1;
+  const uint32_t ca = (uint32_t)(a1 - a0), cb = (uint32_t)(b1 - b0), n = ca + cb;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) sin[i] = i < ca ? a[a0 + i] : b[b0 + (i - ca)];
+  __syncthreads();
+  const uint64_t* la = sin;
+  const uint64_t* lb = sin + ca;
+  const uint32_t diag = threadIdx.x * MERGE_PT;
+  if (diag < n) {
+    uint32_t i = (uint32_t)merge_split(la, ca, lb, cb, diag), j = diag - i;
+    const uint32_t end = diag + MERGE_PT < n ? diag + MERGE_PT : n;
+    for (uint32_t o = diag; o < end; ++o) {
+      const bool take_a = j >= cb || (i < ca && la[i] <= lb[j]);
+      sout[o] = take_a ? la[i++] : lb[j++];
+    }
   }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 256) out[d0 + i] = sout[i];
 }
 
 // merge `ns` staged rows (columns skey/ssid/soff, not freed here) into the active segment
@@ -387,8 +411,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
       // merge the two runs -- one pass over the segment instead of a radix sort of all of it
       SHZ_TRY(shz_sort_u64(ctx, ka + t->n, kb + t->n, nullptr, nullptr, 0, ns, 0, 32 + sb + ob, &sel));
       if (sel) SHZ_HIP(ctx, hipMemcpyAsync(ka + t->n, kb + t->n, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      const uint64_t nthreads = (total + MERGE_PT - 1) / MERGE_PT;
-      hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((total + MERGE_TILE - 1) / MERGE_TILE)), dim3(256), 0, ctx->stream,
                          (const uint64_t*)ka, t->n, (const uint64_t*)(ka + t->n), ns, kb);
       SHZ_HIP(ctx, hipGetLastError());
       std::swap(ka, kb);
