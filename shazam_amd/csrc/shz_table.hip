@@ -1331,6 +1331,62 @@ static int32_t stage_select_shard(shz_table* t, uint32_t nsh, uint32_t want, uin
   return SHZ_OK;
 }
 
+// one-pass partition of the staged rows by destination shard: pack (shard | key) with (sid | off) as payload, ONE
+// stable radix pass on the shard bits, unpack -- instead of one compaction per destination
+__global__ void tbl_shard_pack_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
+                                      const uint32_t* __restrict__ off, uint64_t n, uint32_t nsh, uint64_t* __restrict__ k,
+                                      uint64_t* __restrict__ v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  k[i] = ((uint64_t)shard_of(key[i], nsh) << 32) | key[i];
+  v[i] = ((uint64_t)sid[i] << 32) | off[i];
+}
+__global__ void tbl_shard_unpack_kernel(const uint64_t* __restrict__ k, const uint64_t* __restrict__ v, uint64_t n,
+                                        uint32_t* __restrict__ ok, uint32_t* __restrict__ os, uint32_t* __restrict__ oo,
+                                        unsigned long long* __restrict__ start /* [nsh]: first row of every shard */) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t kk = k[i], vv = v[i];
+  ok[i] = (uint32_t)kk;
+  os[i] = (uint32_t)(vv >> 32);
+  oo[i] = (uint32_t)vv;
+  const uint32_t sh = (uint32_t)(kk >> 32);
+  if (i == 0 || (uint32_t)(k[i - 1] >> 32) != sh) start[sh] = i;
+}
+
+// staged rows of `t` -> (ok, os, oo) grouped by destination shard 0, 1, ...; cnt[d] rows go to shard d
+static int32_t stage_partition(shz_table* t, uint32_t nsh, uint32_t* ok, uint32_t* os, uint32_t* oo, std::vector<uint64_t>& cnt) {
+  shz_ctx* ctx = t->ctx;
+  const uint64_t ns = t->ns;
+  cnt.assign(nsh, 0);
+  if (ns == 0) return SHZ_OK;
+  void *k0, *k1, *v0, *v1, *st;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, ns * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, ns * 8, &k1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, ns * 8, &v0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, ns * 8, &v1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 8ull * nsh, &st));
+  SHZ_HIP(ctx, hipMemsetAsync(st, 0xFF, 8ull * nsh, ctx->stream));
+  hipLaunchKernelGGL(tbl_shard_pack_kernel, dim3(nblk(ns)), dim3(256), 0, ctx->stream, (const uint32_t*)t->skey,
+                     (const uint32_t*)t->ssid, (const uint32_t*)t->soff, ns, nsh, (uint64_t*)k0, (uint64_t*)v0);
+  SHZ_HIP(ctx, hipGetLastError());
+  int sel = 0;
+  if (nsh > 1) SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)k0, (uint64_t*)k1, v0, v1, 8, ns, 32, 32 + bits_for(nsh - 1), &sel));
+  hipLaunchKernelGGL(tbl_shard_unpack_kernel, dim3(nblk(ns)), dim3(256), 0, ctx->stream,
+                     (const uint64_t*)(sel ? k1 : k0), (const uint64_t*)(sel ? v1 : v0), ns, ok, os, oo, (unsigned long long*)st);
+  SHZ_HIP(ctx, hipGetLastError());
+  std::vector<uint64_t> start(nsh);
+  SHZ_HIP(ctx, hipMemcpyAsync(start.data(), st, 8ull * nsh, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t next = ns;  // shards without rows start where the next one does
+  for (int d = (int)nsh - 1; d >= 0; --d) {
+    if (start[d] == ~0ull) start[d] = next;
+    cnt[d] = next - start[d];
+    next = start[d];
+  }
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t nshards) {
   if (!t) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
@@ -1339,12 +1395,15 @@ extern "C" int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t n
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   dev_cols g;
   if (!g.alloc(t->ns)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "keep_shard: hipMalloc(%llu) failed", (unsigned long long)(t->ns * 4));
-  uint64_t kept = 0;
-  SHZ_TRY(stage_select_shard(t, nshards, shard, g.p[0], g.p[1], g.p[2], &kept));
-  void* olds[] = {t->skey, t->ssid, t->soff};
-  for (void* p : olds) SHZ_HIP(ctx, hipFree(p));
-  t->skey = g.take(0); t->ssid = g.take(1); t->soff = g.take(2);
-  t->scap = t->ns;
+  std::vector<uint64_t> cnt;
+  SHZ_TRY(stage_partition(t, nshards, g.p[0], g.p[1], g.p[2], cnt));   // the same partition the exchange uses
+  uint64_t first = 0;
+  for (uint32_t d = 0; d < shard; ++d) first += cnt[d];
+  const uint64_t kept = cnt[shard];
+  uint32_t* dst[3] = {t->skey, t->ssid, t->soff};                      // the staged columns are big enough
+  for (int i = 0; i < 3; ++i)
+    if (kept) SHZ_HIP(ctx, hipMemcpyAsync(dst[i], g.p[i] + first, kept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->ns = kept;
   return SHZ_OK;
 }
@@ -1360,15 +1419,9 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   dev_cols sndc, rcvc;
   if (!sndc.alloc(ns)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shard exchange: hipMalloc(%llu) failed", (unsigned long long)(ns * 4));
   uint32_t** snd = sndc.p;
-  std::vector<uint64_t> scnt(nranks, 0), sdis(nranks, 0);
-  uint64_t pos = 0;
-  for (int d = 0; d < nranks && ns; ++d) {
-    uint64_t k = 0;
-    SHZ_TRY(stage_select_shard(t, (uint32_t)nranks, (uint32_t)d, snd[0] + pos, snd[1] + pos, snd[2] + pos, &k));
-    scnt[d] = k;
-    sdis[d] = pos;
-    pos += k;
-  }
+  std::vector<uint64_t> scnt, sdis(nranks, 0);
+  SHZ_TRY(stage_partition(t, (uint32_t)nranks, snd[0], snd[1], snd[2], scnt));
+  for (int d = 1; d < nranks; ++d) sdis[d] = sdis[d - 1] + scnt[d - 1];
   // 2) everyone learns the whole count matrix: row r = what rank r sends to each destination
   void* d_cnt;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * nranks * (nranks + 1), &d_cnt));

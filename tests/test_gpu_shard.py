@@ -164,3 +164,31 @@ def test_one_rank_communicator_paths():
     sh.close()
     one.close()
     comm.close()
+
+
+def test_one_pass_partition_via_keep_shard():
+    """shz_table_keep_shard runs the one-pass partition of the shard exchange (pack, one radix pass on the shard bits,
+    unpack) and keeps one slice: over all shards the slices are disjoint, complete and agree with shard_of_keys."""
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    from shazam_amd.shard import shard_of_keys
+    ctx = S.get_context(0)
+    rng = np.random.default_rng(77)
+    k, s, o = _rows(rng, 90001, nsongs=5000, noff=70000)
+    want = np.unique(np.stack([k, s, o], 1).astype(np.uint64), axis=0)
+    for nsh in (2, 5, 8):
+        got = []
+        for sh in range(nsh):
+            t = S.Table(ctx)
+            t.insert(k, s, o)
+            ctx.check(_ffi.lib().shz_table_keep_shard(t.h, sh, nsh))
+            kept = t.rows()[1]
+            assert kept == int((shard_of_keys(k, nsh) == sh).sum())
+            t.finalize()
+            ek, es, eo = t.export()
+            assert np.all(shard_of_keys(ek, nsh) == sh)
+            got.append(np.stack([ek, es, eo], 1).astype(np.uint64))
+            t.close()
+        allrows = np.concatenate(got)
+        assert len(allrows) == len(want)
+        assert np.array_equal(np.unique(allrows, axis=0), want)
