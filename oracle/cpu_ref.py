@@ -113,11 +113,18 @@ def _running_max(a: np.ndarray, r: int, axis: int) -> np.ndarray:
 
 
 def peaks_2d(A: np.ndarray, amp_min: float = DEFAULT_AMP_MIN, r: int = PEAK_NEIGHBORHOOD_SIZE):
-    """get_2D_peaks (__init__.py:116-177) net effect, proven in SURVEY 8a row 4:
-    peak <=> A[f,t] == max(A[f-r..f+r, t-r..t+r] within the array) and A[f,t] > amp_min.
+    """get_2D_peaks (__init__.py:116-177):
+    peak <=> A[f,t] == max(A[f-r..f+r, t-r..t+r] within the array) and A[f,t] > amp_min,
+    except zero-valued cells whose whole window is zero (`local_max != binary_erosion(A == 0, ..., border_value=1)`,
+    __init__.py:147-151: the XOR removes local maxima that are eroded background; outside the array counts as zero).
+    For amp_min >= 0 the exception is void -- such cells fail `> amp_min` anyway.
     Returns (freqs, times) int64 arrays in np.where row-major order (freq asc, time asc)."""
     m = _running_max(_running_max(A, r, 0), r, 1)
     det = (m == A) & (A > amp_min)
+    if amp_min < 0:
+        nz = (A != 0).astype(np.float64)                       # any non-zero cell in the (clipped) window?
+        any_nz = _running_max(_running_max(nz, r, 0), r, 1) > 0
+        det &= ~((A == 0) & ~any_nz)
     f, t = np.where(det)
     return f.astype(np.int64), t.astype(np.int64)
 

@@ -421,6 +421,51 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   }
 }
 
+// amp_min < 0 only: the reference drops local maxima that sit inside a region of exact zeros.  get_2D_peaks marks
+// `local_max != binary_erosion(arr2D == 0, 21x21, border_value=1)` (__init__.py:147-151): a zero-valued cell whose whole
+// 21x21 window (clipped to the clip; outside counts as zero) is zero is a local maximum AND eroded background, the XOR
+// removes it.  For amp_min >= 0 such cells never pass `> amp_min`; below zero they would, so their mask bits are cleared
+// here, before the scan.  ZERO is 0.0 on a dB array and 1.0 on the power array (zero power is stored as 1.0 = 0 dB).
+__global__ __launch_bounds__(256) void peak_zero_plateau_kernel(uint64_t* __restrict__ mask, uint64_t n_words,
+                                                                uint32_t n_slabs, const double* __restrict__ A,
+                                                                uint32_t row_stride, uint32_t n_bins, double zero,
+                                                                const uint32_t* __restrict__ clip_foff,
+                                                                uint32_t n_clips) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint64_t m0 = mask[w];
+  if (!m0) return;
+  const uint32_t per_frame = n_slabs * 4;
+  const uint32_t g = (uint32_t)(w / per_frame);
+  const uint32_t rem = (uint32_t)(w % per_frame);
+  const uint32_t slab = rem >> 2, wv = rem & 3;
+  uint32_t lo = 0, hi = n_clips;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (clip_foff[mid] <= g) lo = mid; else hi = mid;
+  }
+  const int t = (int)(g - clip_foff[lo]), F = (int)(clip_foff[lo + 1] - clip_foff[lo]);
+  uint64_t m = m0, keep = m0;
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int col = (int)(slab * PK_SW + wv * 63) + b - 10;
+    const double* centre = A + (uint64_t)g * row_stride + col;
+    if (*centre != zero) continue;
+    bool all_zero = true;
+    for (int dt = -10; dt <= 10 && all_zero; ++dt) {
+      if (t + dt < 0 || t + dt >= F) continue;
+      for (int df = -10; df <= 10; ++df) {
+        const int c = col + df;
+        if (c < 0 || c >= (int)n_bins) continue;
+        if (centre[(long long)dt * row_stride + df] != zero) { all_zero = false; break; }
+      }
+    }
+    if (all_zero) keep &= ~(1ull << b);
+  }
+  if (keep != m0) mask[w] = keep;
+}
+
 // K3: expand peak masks into the ordered peak list.  One thread per mask word.
 __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __restrict__ mask,
                                                           const uint32_t* __restrict__ word_off, uint64_t n_words,
@@ -692,6 +737,11 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
     else
       hipLaunchKernelGGL(peak_pick_kernel<false>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
                          n_bins, sd.d_segs, n_slabs, amp_min, 0.0, 0.0, (uint64_t*)d_mask);
+    SHZ_HIP(ctx, hipGetLastError());
+  }
+  if (amp_min < 0.0 && n_words) {  // see peak_zero_plateau_kernel
+    hipLaunchKernelGGL(peak_zero_plateau_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (uint64_t*)d_mask, n_words, n_slabs, d_db, row_stride, n_bins, is_power ? 1.0 : 0.0, sd.d_foff, nc);
     SHZ_HIP(ctx, hipGetLastError());
   }
   uint64_t tot = 0;
