@@ -9,10 +9,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def zero_region_arrays():   # same arrays as tests/test_amp_min_domain.py (kept local: test files do not import each other)
+    rng = np.random.default_rng(0)
+    A = rng.normal(0, 5, (60, 80))
+    A[10:40, 20:60] = 0.0
+    A[5, 5] = 0.0
+    B = -np.abs(rng.normal(0, 5, (70, 90)))
+    B[:25, :30] = 0.0
+    B[40:48, 50:58] = 0.0
+    return {"A": A, "B": B, "C": np.zeros((30, 40))}
+
+
 def test_array_api_zero_plateaus():
     import shazam_amd as S
     from oracle import thirdparty_ref as T
-    from tests.test_amp_min_domain import zero_region_arrays
     for name, X in zero_region_arrays().items():
         for amp_min in (10, 0, -0.5, -20):
             with warnings.catch_warnings():
