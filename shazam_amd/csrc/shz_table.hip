@@ -1008,6 +1008,99 @@ __global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict_
   if (threadIdx.x == 0) out_nres[q] = found;
 }
 
+// Two-level form of m_topn_kernel for queries with millions of (query, song) groups (a 1M-song table yields ~9M per
+// 10 s query, and only a few dozen queries fit one vote pass): with one workgroup per query the scan of g_pack ran on
+// a few dozen workgroups.  Level 1: workgroup (c, q) finds the top-n of slice c of query q's runs; level 2: one
+// workgroup per query ranks the C x topn candidates.  g_pack is unique per group, so "strictly below the previous
+// winner" selects the same groups as the single-level kernel.
+__device__ __forceinline__ void topn_block_max(uint64_t& best, uint32_t& bestr, uint64_t* s_best, uint32_t* s_r) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint64_t ob = (uint64_t)__shfl_xor((long long)best, d, 64);
+    const uint32_t orr = (uint32_t)__shfl_xor((int)bestr, d, 64);
+    if (ob > best) { best = ob; bestr = orr; }
+  }
+  if (lane == 0) { s_best[wave] = best; s_r[wave] = bestr; }
+  __syncthreads();
+  best = s_best[0]; bestr = s_r[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (s_best[w] > best) { best = s_best[w]; bestr = s_r[w]; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void m_topn_partial_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
+                                                             uint32_t nr, m_bits mb, const uint64_t* __restrict__ g_pack,
+                                                             uint32_t topn, uint64_t* __restrict__ part_pack,
+                                                             uint32_t* __restrict__ part_r) {
+  __shared__ uint64_t s_best[4];
+  __shared__ uint32_t s_r[4];
+  const uint32_t q = blockIdx.y, c = blockIdx.x, C = gridDim.x;
+  const int qshift = mb.sb + mb.dbits + 1;
+  auto lb = [&](uint64_t target) {
+    uint32_t l = 0, h = nr;
+    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if ((v[rs[mid]] >> qshift) < target) l = mid + 1; else h = mid; }
+    return l;
+  };
+  const uint32_t r0 = lb(q), r1 = lb((uint64_t)q + 1);
+  const uint32_t S = (r1 - r0 + C - 1) / C;
+  const uint32_t a = r0 + (uint32_t)min((uint64_t)c * S, (uint64_t)(r1 - r0));
+  const uint32_t b = (uint32_t)min((uint64_t)a + S, (uint64_t)r1);
+  uint64_t prev = ~0ull;
+  const uint64_t o = ((uint64_t)q * C + c) * topn;
+  for (uint32_t n = 0; n < topn; ++n) {
+    uint64_t best = 0;
+    uint32_t bestr = 0xFFFFFFFFu;
+    if (prev) {
+      for (uint32_t r = a + threadIdx.x; r < b; r += 256) {
+        const uint64_t packed = g_pack[r];
+        if (packed < prev && packed > best) { best = packed; bestr = r; }
+      }
+    }
+    topn_block_max(best, bestr, s_best, s_r);
+    if (threadIdx.x == 0) { part_pack[o + n] = best; part_r[o + n] = bestr; }
+    prev = best;  // 0 once the slice is exhausted: the remaining slots are written as 0
+  }
+}
+
+__global__ __launch_bounds__(256) void m_topn_final_kernel(const uint64_t* __restrict__ part_pack,
+                                                           const uint32_t* __restrict__ part_r, uint32_t ncand, m_bits mb,
+                                                           const uint32_t* __restrict__ g_delta,
+                                                           const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
+                                                           uint32_t* __restrict__ out_sid, int32_t* __restrict__ out_delta,
+                                                           uint32_t* __restrict__ out_aligned, uint32_t* __restrict__ out_dedup,
+                                                           uint32_t* __restrict__ out_nres) {
+  __shared__ uint64_t s_best[4];
+  __shared__ uint32_t s_r[4];
+  const uint32_t q = blockIdx.x;
+  if (q >= nq) return;
+  const uint64_t* pp = part_pack + (uint64_t)q * ncand;
+  const uint32_t* pr = part_r + (uint64_t)q * ncand;
+  uint64_t prev = ~0ull;
+  uint32_t found = 0;
+  for (uint32_t n = 0; n < topn; ++n) {
+    uint64_t best = 0;
+    uint32_t bestr = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < ncand; i += 256) {
+      const uint64_t packed = pp[i];
+      if (packed < prev && packed > best) { best = packed; bestr = pr[i]; }
+    }
+    topn_block_max(best, bestr, s_best, s_r);
+    if (best == 0) break;  // uniform
+    if (threadIdx.x == 0) {
+      const uint64_t o = (uint64_t)q * topn + n;
+      out_sid[o] = 0xFFFFFFFFu - (uint32_t)best;
+      out_aligned[o] = (uint32_t)(best >> 32);
+      out_delta[o] = (int32_t)((int64_t)g_delta[bestr] - (int64_t)mb.bias);
+      out_dedup[o] = g_dedup[bestr];
+    }
+    prev = best;
+    ++found;
+  }
+  if (threadIdx.x == 0) out_nres[q] = found;
+}
+
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 // shz_match_pairs: the packed votes themselves leave match_core (device buffer of `cap` entries), in a key layout
@@ -1044,8 +1137,21 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
                      P, (const uint64_t*)d_tot, (uint32_t*)rs);
   hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (uint64_t*)gh,
                      (uint32_t*)gd, (uint32_t*)gdd);
-  hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (const uint64_t*)gh,
-                     (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
+  // runs per query decide the shape: one workgroup per query, or C slices per query and a final ranking
+  const uint32_t C = (uint32_t)std::min<uint64_t>(512, ((uint64_t)nr / nq + 16383) / 16384);
+  if (C <= 1) {
+    hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (const uint64_t*)gh,
+                       (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
+  } else {
+    void *pp, *pr;
+    const uint64_t ncand = (uint64_t)C * topn;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)nq * ncand * 8, &pp));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nq * ncand * 4, &pr));
+    hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+                       (const uint64_t*)gh, topn, (uint64_t*)pp, (uint32_t*)pr);
+    hipLaunchKernelGGL(m_topn_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint64_t*)pp, (const uint32_t*)pr,
+                       (uint32_t)ncand, mb, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
+  }
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
