@@ -148,8 +148,7 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 }
 
 // ---------------------------------------------------------------------------------------
-// Stable LSD radix sort, 8 bits per pass.  Tile = 256 threads x 16 rounds; round r of a block
-// covers elements [tile + r*256, tile + r*256 + 256) so the in-tile order is the memory order.
+// Stable LSD radix sort, 8 bits per pass.  Tile = 4096 keys per workgroup of 256 threads.
 #define SORT_THREADS 256
 #define SORT_ROUNDS 16
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
@@ -161,10 +160,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
-#pragma unroll 4
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
-    uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  if (base + SORT_TILE <= n) {  // whole tile: all loads in flight (two keys per lane and load) before the first count
+    const ulonglong2* k2 = (const ulonglong2*)(keys + base);
+    ulonglong2 x[SORT_ROUNDS / 2];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 2; ++r) x[r] = k2[r * SORT_THREADS + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 2; ++r) {
+      atomicAdd(&h[(x[r].x >> shift) & 255u], 1u);
+      atomicAdd(&h[(x[r].y >> shift) & 255u], 1u);
+    }
+  } else {
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+      uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
+      if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
   }
   __syncthreads();
   hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -173,9 +183,12 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
 template <int VB> struct val_t { typedef uint32_t type; };
 template <> struct val_t<8> { typedef uint64_t type; };
 
-// Scatter of one pass.  The tile (4096 keys) is first re-ordered by digit inside LDS (stable: rounds in
-// memory order, ballot ranks inside a wave, wave prefixes across waves), then written out so that each
-// digit's run is one contiguous, coalesced global segment instead of 4096 scattered 8-byte stores.
+// Scatter of one pass.  The tile (4096 keys) is first re-ordered by digit inside LDS, then written out so that each
+// digit's run is one contiguous, coalesced global segment instead of 4096 scattered 8-byte stores.  Stable: wave w owns
+// the w-th quarter of the tile in memory order (16 rows of 64 keys, all loaded up front so that one memory latency
+// covers the tile); a key's slot = first slot of its digit + keys of that digit in earlier waves + its rank among the
+// wave's own keys of that digit (ballot rank inside a row + the wave's running count, which only that wave touches:
+// LDS operations of one wave execute in order, so the rows need no barrier).
 template <int VB>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys,
                                                                      const void* __restrict__ vals_,
@@ -190,12 +203,22 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   __shared__ V sval[VB ? SORT_TILE : 1];
   __shared__ uint32_t lstart[256];       // first LDS slot of each digit's run
   __shared__ uint32_t gbase[256];        // first global slot of each digit's run of this tile
-  __shared__ uint32_t running[256];      // LDS write cursor per digit
-  __shared__ uint32_t cnt[4][256];       // per-wave digit counts of the current round
+  __shared__ uint32_t wrun[4][256];      // per wave: running digit counts, then the first slot of the wave's keys per digit
   __shared__ uint32_t scan_tmp[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
   const uint32_t tile_n = (uint32_t)(n - base < SORT_TILE ? n - base : SORT_TILE);
+  constexpr int ROWS = SORT_TILE / SORT_THREADS;   // rows of 64 keys per wave
+  uint64_t k[ROWS];
+  V pv[VB ? ROWS : 1];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    k[r] = li < tile_n ? keys[base + li] : 0;
+    if (VB != 0) pv[r] = li < tile_n ? vals[base + li] : 0;
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wrun[w][threadIdx.x] = 0;
   {  // digit counts of this tile from the scanned histogram: next flattened entry minus this one
     const uint64_t f = (uint64_t)threadIdx.x * nblocks + blockIdx.x;
     const uint32_t g0 = offs[f];
@@ -204,49 +227,52 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
     const uint32_t ls = block_excl_scan<uint32_t>(g1 - g0, &tot, scan_tmp);
     gbase[threadIdx.x] = g0;
     lstart[threadIdx.x] = ls;
-    running[threadIdx.x] = ls;
   }
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
-    const uint32_t li = (uint32_t)r * SORT_THREADS + threadIdx.x;
-    if ((uint32_t)r * SORT_THREADS >= tile_n) break;  // uniform
+  __syncthreads();
+  uint32_t rank[ROWS];
+  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
-    __syncthreads();
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
-    uint64_t k = valid ? keys[base + li] : 0;
-    V v = 0;
-    if (VB != 0 && valid) v = vals[base + li];
-    const uint32_t d = (uint32_t)(k >> shift) & 255u;
-    // lanes of this wave holding the same digit (invalid lanes form their own class)
-    unsigned long long peers = __ballot(valid);
-    if (!valid) peers = ~peers;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);   // valid lanes of this row holding the same digit
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      unsigned long long m = __ballot((d >> b) & 1u);
+      const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t rank = (uint32_t)__popcll(peers & lt);
-    if (valid && rank == 0) cnt[wave][d] = (uint32_t)__popcll(peers);
-    __syncthreads();
-    uint32_t pos = 0;
-    if (valid) {
-      pos = running[d] + rank;
-      for (int w = 0; w < wave; ++w) pos += cnt[w][d];
-    }
-    __syncthreads();
-    running[threadIdx.x] += cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
-    if (valid) {
-      skey[pos] = k;
-      if (VB != 0) sval[pos] = v;
+    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    const uint32_t run = wrun[wave][d];
+    rank[r] = run + rk;
+    if (valid && rk == 0) wrun[wave][d] = run + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = wrun[0][threadIdx.x], c1 = wrun[1][threadIdx.x], c2 = wrun[2][threadIdx.x];
+    const uint32_t ls = lstart[threadIdx.x];
+    wrun[0][threadIdx.x] = ls;
+    wrun[1][threadIdx.x] = ls + c0;
+    wrun[2][threadIdx.x] = ls + c0 + c1;
+    wrun[3][threadIdx.x] = ls + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    if (li < tile_n) {
+      const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+      const uint32_t pos = wrun[wave][d] + rank[r];
+      skey[pos] = k[r];
+      if (VB != 0) sval[pos] = pv[r];
     }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
-    const uint64_t k = skey[i];
-    const uint32_t d = (uint32_t)(k >> shift) & 255u;
+    const uint64_t kk = skey[i];
+    const uint32_t d = (uint32_t)(kk >> shift) & 255u;
     const uint32_t g = gbase[d] + (i - lstart[d]);
-    okeys[g] = k;
+    okeys[g] = kk;
     if (VB != 0) ovals[g] = sval[i];
   }
 }

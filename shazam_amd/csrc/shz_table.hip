@@ -820,51 +820,50 @@ __global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const ui
   if (i < n && flag[i]) starts[pos[i]] = (uint32_t)i;
 }
 
-// probe: rows [lo, lo+rows) of every (query, key) group in every segment; g_lo / g_rows are [nseg][ng+1]
+// probe: rows [lo, lo+rows) of every (query, key) group g in every segment sg, one thread per x = g * nseg + sg.
+// g_lo[x] = first row, g_pairs[x] = rows x offsets of the group (the votes it expands to); x = ng * nseg is the
+// sentinel that makes the exclusive scan end in the total.
 __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
-                               const shz_seg_dev* __restrict__ segs, int nseg, uint32_t* __restrict__ g_lo,
-                               uint32_t* __restrict__ g_rows, uint64_t* __restrict__ g_pairs,
-                               unsigned long long* __restrict__ rows_total) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long rows_all = 0;
-  if (g < ng) {
+                               const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint32_t* __restrict__ g_lo,
+                               uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total) {
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t nx = (uint64_t)ng * nseg;
+  unsigned long long s = 0;
+  if (x < nx) {
+    const uint32_t g = (uint32_t)(x / nseg), sg = (uint32_t)(x - (uint64_t)g * nseg);
     const uint32_t e0 = gs[g];
     const uint32_t key = (uint32_t)(E[e0] >> QKEY_SHIFT);
     const uint64_t b = key >> 8;
-    for (int sg = 0; sg < nseg; ++sg) {
-      const uint32_t* __restrict__ tkey = segs[sg].key;
-      uint32_t lo = 0, rows = 0;
-      if (b < segs[sg].nbuckets && segs[sg].n) {
-        uint32_t l = segs[sg].bucket[b], h = segs[sg].bucket[b + 1];
-        const uint32_t h0 = h;
-        while (l < h) {  // lower_bound(key)
-          uint32_t mid = l + ((h - l) >> 1);
-          if (tkey[mid] < key) l = mid + 1; else h = mid;
-        }
-        lo = l;
-        h = h0;
-        while (l < h) {  // upper_bound(key)
-          uint32_t mid = l + ((h - l) >> 1);
-          if (tkey[mid] <= key) l = mid + 1; else h = mid;
-        }
-        rows = l - lo;
+    const uint32_t* __restrict__ tkey = segs[sg].key;
+    uint32_t lo = 0, rows = 0;
+    if (b < segs[sg].nbuckets && segs[sg].n) {
+      uint32_t l = segs[sg].bucket[b], h = segs[sg].bucket[b + 1];
+      const uint32_t h0 = h;
+      while (l < h) {  // lower_bound(key)
+        uint32_t mid = l + ((h - l) >> 1);
+        if (tkey[mid] < key) l = mid + 1; else h = mid;
       }
-      g_lo[(uint64_t)sg * (ng + 1) + g] = lo;
-      g_rows[(uint64_t)sg * (ng + 1) + g] = rows;
-      rows_all += rows;
+      lo = l;
+      h = h0;
+      while (l < h) {  // upper_bound(key)
+        uint32_t mid = l + ((h - l) >> 1);
+        if (tkey[mid] <= key) l = mid + 1; else h = mid;
+      }
+      rows = l - lo;
     }
-    g_pairs[g] = rows_all * (gs[g + 1] - e0);
-  } else if (g == ng) {
-    g_pairs[g] = 0;  // sentinel so the exclusive scan yields po[ng] = total
+    g_lo[x] = lo;
+    g_pairs[x] = (uint64_t)rows * (gs[g + 1] - e0);
+    s = rows;
+  } else if (x == nx) {
+    g_pairs[x] = 0;
   }
-  unsigned long long s = rows_all;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor((long long)s, d, 64);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total, s);
 }
 
 __global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu, const uint32_t* __restrict__ gs,
-                                     uint32_t ng, const uint64_t* __restrict__ po, uint32_t nq,
+                                     uint32_t ng, const uint64_t* __restrict__ po, uint32_t nseg, uint32_t nq,
                                      uint32_t* __restrict__ nhash, uint64_t* __restrict__ npairs) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
@@ -881,80 +880,242 @@ __global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu
   };
   const uint64_t a = (uint64_t)q << QIDX_SHIFT, b = (uint64_t)(q + 1) << QIDX_SHIFT;
   nhash[q] = lb_e(b) - lb_e(a);
-  npairs[q] = po[lb_g(b)] - po[lb_g(a)];
+  npairs[q] = po[(uint64_t)lb_g(b) * nseg] - po[(uint64_t)lb_g(a) * nseg];
 }
 
 struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset of the sub-batch: delta + bias >= 0
 
-__global__ void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
-                                const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
-                                const uint32_t* __restrict__ g_rows, const shz_seg_dev* __restrict__ segs, int nseg,
-                                uint64_t P, m_bits mb, uint32_t q_base, uint64_t* __restrict__ v) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  uint32_t l = 0, h = ng;  // last g with po[g] <= p
-  while (h - l > 1) {
-    uint32_t mid = (l + h) >> 1;
-    if (po[mid] <= p) l = mid; else h = mid;
+// last g in [0, ng) with po[g] <= p, by the 64 lanes of one wave (po is ascending, po[0] = 0): 64-ary steps
+__device__ __forceinline__ uint32_t m_wave_search(const uint64_t* __restrict__ po, uint32_t ng, uint64_t p) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t lo = 0, n = ng;
+  while (n > 1) {
+    const uint32_t step = (n + 63) / 64;
+    const uint32_t idx = lo + lane * step;
+    const bool ok = lane * step < n && po[idx] <= p;   // a prefix of the lanes (lane 0 always)
+    const unsigned long long b = __ballot(ok);
+    const uint32_t last = 63u - (uint32_t)__clzll(b);
+    n = min(step, n - last * step);
+    lo += last * step;
   }
-  const uint32_t g = l;
-  const uint32_t e0 = gs[g], noff = gs[g + 1] - e0;
-  const uint64_t r = p - po[g];
-  uint64_t ridx = r / noff;  // row number inside the group's rows, segment after segment
-  const uint32_t oi = (uint32_t)(r % noff);
-  int sg = 0;
-  for (; sg < nseg - 1; ++sg) {
-    const uint32_t rs_ = g_rows[(uint64_t)sg * (ng + 1) + g];
-    if (ridx < rs_) break;
-    ridx -= rs_;
-  }
-  const uint32_t row = g_lo[(uint64_t)sg * (ng + 1) + g] + (uint32_t)ridx;
-  const uint32_t* __restrict__ tsid = segs[sg].sid;
-  const uint32_t* __restrict__ toff = segs[sg].off;
-  const uint64_t e = E[e0 + oi];
-  const uint64_t q = (e >> QIDX_SHIFT) + q_base;
-  const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
-  const uint64_t dprime = (uint64_t)toff[row] + mb.bias - qo;  // delta + bias >= 0
-  v[p] = ((((q << mb.sb) | tsid[row]) << mb.dbits | dprime) << 1) | (oi == 0 ? 1u : 0u);
+  return lo;
 }
 
-// one thread per run that opens a (query, sid) group: fold its runs (ascending delta) into
-// (best count, first delta reaching it, dedup rows)
-__global__ void m_group_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs, uint32_t nr, m_bits mb,
-                               uint64_t* __restrict__ g_pack, uint32_t* __restrict__ g_delta,
-                               uint32_t* __restrict__ g_dedup) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nr) return;
-  const int gshift = mb.dbits + 1;
-  const uint64_t grp = v[rs[r]] >> gshift;
-  const bool head = r == 0 || (v[rs[r - 1]] >> gshift) != grp;
-  if (!head) { g_pack[r] = 0; return; }   // 0 never wins: a real group has count >= 1
-  const uint64_t dmask = (1ull << mb.dbits) - 1;
-  uint32_t best = 0, bestd = 0, cur = 0, dedup = 0;
-  uint64_t curd = ~0ull;
-  for (uint32_t k = r; k < nr; ++k) {
-    const uint64_t val = v[rs[k]];
-    if ((val >> gshift) != grp) break;
-    const uint32_t len = rs[k + 1] - rs[k];
-    const uint64_t d = (val >> 1) & dmask;
-    if (d != curd) {
-      if (cur > best) { best = cur; bestd = (uint32_t)curd; }
-      curd = d;
-      cur = 0;
-    }
-    cur += len;
-    if (val & 1) dedup += len;
+// expand: pair p = (query hash element, table row) of sub-group x = (group g, segment sg), packed as a vote.  A
+// workgroup owns M_EXP_TILE consecutive pairs: two waves find the sub-groups of its first and last pair, every thread
+// then searches only between them (a tile spans a handful of sub-groups, the whole po[] has ~1e6 entries), all of a
+// thread's pairs in lockstep so that their loads overlap.
+#define M_EXP_PER 8
+#define M_EXP_TILE (256 * M_EXP_PER)
+__global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                                       uint32_t nx, const uint64_t* __restrict__ po,
+                                                       const uint32_t* __restrict__ g_lo,
+                                                       const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t P,
+                                                       m_bits mb, uint32_t q_base, uint64_t* __restrict__ v) {
+  __shared__ uint32_t s_x[2];
+  const uint64_t base = (uint64_t)blockIdx.x * M_EXP_TILE;
+  const uint64_t last = min(base + M_EXP_TILE, P) - 1;
+  const int wave = threadIdx.x >> 6;
+  if (wave < 2) {
+    const uint32_t x = m_wave_search(po, nx, wave ? last : base);
+    if ((threadIdx.x & 63) == 0) s_x[wave] = x;
   }
-  if (cur > best) { best = cur; bestd = (uint32_t)curd; }
-  const uint32_t sid = (uint32_t)(grp & ((1ull << mb.sb) - 1));
-  g_pack[r] = ((uint64_t)best << 32) | (0xFFFFFFFFu - sid);   // rank: count desc, then sid asc
-  g_delta[r] = bestd;
-  g_dedup[r] = dedup;
+  __syncthreads();
+  const uint32_t xA = s_x[0], xB = s_x[1];
+  int iters = 0;
+  while ((1u << iters) < xB - xA + 1) ++iters;  // uniform
+  uint64_t p[M_EXP_PER];
+  uint32_t l[M_EXP_PER], h[M_EXP_PER];
+#pragma unroll
+  for (int j = 0; j < M_EXP_PER; ++j) {
+    p[j] = min(base + (uint64_t)j * 256 + threadIdx.x, last);  // clamped: lanes past the end redo the last pair, unstored
+    l[j] = xA;
+    h[j] = xB + 1;  // last x in [xA, xB] with po[x] <= p
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < M_EXP_PER; ++j) {
+      const uint32_t mid = (l[j] + h[j]) >> 1;   // == l once h - l <= 1: po[l] <= p keeps l
+      if (po[mid] <= p[j]) l[j] = mid; else h[j] = mid;
+    }
+  }
+  uint32_t row[M_EXP_PER], sg[M_EXP_PER], flag[M_EXP_PER];
+  uint64_t e[M_EXP_PER];
+#pragma unroll
+  for (int j = 0; j < M_EXP_PER; ++j) {
+    const uint32_t x = l[j];
+    const uint32_t g = x / nseg;
+    sg[j] = x - g * nseg;
+    const uint32_t e0 = gs[g], noff = gs[g + 1] - e0;
+    const uint32_t r = (uint32_t)(p[j] - po[x]);  // < P < 2^32
+    uint32_t ridx = r, oi = 0;                    // row number inside the sub-group's rows, offset of the hash
+    if (noff != 1) { ridx = r / noff; oi = r - ridx * noff; }
+    row[j] = g_lo[x] + ridx;
+    e[j] = E[e0 + oi];
+    flag[j] = oi == 0 ? 1u : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < M_EXP_PER; ++j) {
+    const uint32_t* __restrict__ tsid = segs[sg[j]].sid;
+    const uint32_t* __restrict__ toff = segs[sg[j]].off;
+    const uint64_t q = (e[j] >> QIDX_SHIFT) + q_base;
+    const uint32_t qo = (uint32_t)e[j] & ((1u << QOFF_BITS) - 1);
+    const uint64_t dprime = (uint64_t)toff[row[j]] + mb.bias - qo;  // delta + bias >= 0
+    const uint64_t out = ((((q << mb.sb) | tsid[row[j]]) << mb.dbits | dprime) << 1) | flag[j];
+    const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
+    if (pj < P) v[pj] = out;
+  }
+}
+
+// ---- fold of the sorted votes into one record per (query, sid) group
+// The votes are sorted by (query, sid, delta, flag).  A thread owns RG_PER consecutive votes and every group whose FIRST
+// vote lies among them; it follows such a group past its own votes to the group's end (groups average a few votes, the
+// true match a few hundred).  Record = (best count of one delta, smallest delta reaching it, votes with the
+// first-offset flag = rows matched).  Records are written densely in group order: m_gcount_kernel counts the heads
+// per wave, a scan of those counts gives every wave its first slot.
+#define RG_PER 8
+
+__device__ __forceinline__ int rg_load(const uint64_t* __restrict__ v, uint64_t i0, uint64_t P, uint64_t (&e)[RG_PER]) {
+  if (i0 + RG_PER <= P) {
+    const ulonglong2* p2 = (const ulonglong2*)(v + i0);
+#pragma unroll
+    for (int j = 0; j < RG_PER / 2; ++j) { const ulonglong2 x = p2[j]; e[2 * j] = x.x; e[2 * j + 1] = x.y; }
+    return RG_PER;
+  }
+  const int n = i0 < P ? (int)(P - i0) : 0;
+#pragma unroll
+  for (int j = 0; j < RG_PER; ++j) e[j] = j < n ? v[i0 + j] : 0;
+  return n;
+}
+
+// the vote before a thread's first one: the neighbour lane's last vote, or memory for lane 0 (0 = "none" for i0 == 0)
+__device__ __forceinline__ uint64_t rg_prev(const uint64_t* __restrict__ v, uint64_t i0, uint64_t P, uint64_t e_last) {
+  uint64_t prev = (uint64_t)__shfl_up((long long)e_last, 1, 64);
+  if ((threadIdx.x & 63) == 0) prev = (i0 > 0 && i0 <= P) ? v[i0 - 1] : 0;
+  return prev;
+}
+
+__global__ __launch_bounds__(256) void m_gcount_kernel(const uint64_t* __restrict__ v, uint64_t P, int gshift,
+                                                       uint32_t* __restrict__ wcnt) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i0 = t * RG_PER;
+  uint64_t e[RG_PER];
+  const int n = rg_load(v, i0, P, e);
+  uint64_t prev = rg_prev(v, i0, P, e[RG_PER - 1]);
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < RG_PER; ++j) {
+    if (j < n && (i0 + j == 0 || (e[j] >> gshift) != (prev >> gshift))) ++c;
+    prev = e[j];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor((int)c, d, 64);
+  if ((threadIdx.x & 63) == 0) wcnt[t >> 6] = c;
+}
+
+struct rg_state {
+  uint64_t grp, curd;
+  uint32_t best, bestd, cur, dedup;
+};
+
+__device__ __forceinline__ void rg_add(rg_state& s, uint64_t val, uint64_t dmask) {
+  const uint64_t d = (val >> 1) & dmask;
+  if (d != s.curd) {
+    if (s.cur > s.best) { s.best = s.cur; s.bestd = (uint32_t)s.curd; }
+    s.curd = d;
+    s.cur = 0;
+  }
+  ++s.cur;
+  s.dedup += (uint32_t)(val & 1);
+}
+
+__global__ __launch_bounds__(256) void m_reduce_kernel(const uint64_t* __restrict__ v, uint64_t P, m_bits mb,
+                                                       const uint32_t* __restrict__ wbase, uint64_t* __restrict__ g_pack,
+                                                       uint32_t* __restrict__ g_delta, uint32_t* __restrict__ g_dedup,
+                                                       uint32_t* __restrict__ qstart) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i0 = t * RG_PER;
+  const int gshift = mb.dbits + 1, qshift = mb.sb + mb.dbits + 1;
+  const uint64_t dmask = (1ull << mb.dbits) - 1, smask = (1ull << mb.sb) - 1;
+  uint64_t e[RG_PER];
+  const int n = rg_load(v, i0, P, e);
+  const uint64_t before = rg_prev(v, i0, P, e[RG_PER - 1]);
+  uint32_t hm = 0;  // bit j: vote j opens a group
+  {
+    uint64_t prev = before;
+#pragma unroll
+    for (int j = 0; j < RG_PER; ++j) {
+      if (j < n && (i0 + j == 0 || (e[j] >> gshift) != (prev >> gshift))) hm |= 1u << j;
+      prev = e[j];
+    }
+  }
+  const uint32_t hc = (uint32_t)__popc(hm);
+  uint32_t incl = hc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) incl += o;
+  }
+  if (hm == 0) return;
+  uint32_t slot = wbase[t >> 6] + incl - hc;
+  rg_state s;
+  bool owning = false;
+  auto emit = [&]() {
+    if (s.cur > s.best) { s.best = s.cur; s.bestd = (uint32_t)s.curd; }
+    g_pack[slot] = ((uint64_t)s.best << 32) | (0xFFFFFFFFu - (uint32_t)(s.grp & smask));   // rank: count desc, then sid asc
+    g_delta[slot] = s.bestd;
+    g_dedup[slot] = s.dedup;
+    ++slot;
+  };
+  {
+    uint64_t prev = before;
+#pragma unroll
+    for (int j = 0; j < RG_PER; ++j) {
+      if (j < n) {
+        if ((hm >> j) & 1u) {
+          if (owning) emit();
+          owning = true;
+          s.grp = e[j] >> gshift;
+          s.curd = ~0ull;
+          s.best = s.bestd = s.cur = s.dedup = 0;
+          if (i0 + j == 0 || (e[j] >> qshift) != (prev >> qshift)) qstart[e[j] >> qshift] = slot;  // first group of a query
+        }
+        if (owning) rg_add(s, e[j], dmask);
+      }
+      prev = e[j];
+    }
+  }
+  // the last group may run on past this thread's votes
+  bool open = n == RG_PER;
+  for (uint64_t i = i0 + RG_PER; open && i < P; i += RG_PER) {
+    uint64_t x[RG_PER];
+    const int m = rg_load(v, i, P, x);
+#pragma unroll
+    for (int j = 0; j < RG_PER; ++j) {
+      if (open && j < m) {
+        if ((x[j] >> gshift) != s.grp) open = false; else rg_add(s, x[j], dmask);
+      }
+    }
+    if (m < RG_PER) open = false;
+  }
+  emit();
+}
+
+// group records [r0, r1) of query q: qstart[] holds the first record of every query that has any (0xFFFFFFFF = none)
+__device__ __forceinline__ void m_query_groups(const uint32_t* __restrict__ qstart, uint32_t nq, uint32_t G, uint32_t q,
+                                               uint32_t& r0, uint32_t& r1) {
+  r0 = qstart[q];
+  if (r0 == 0xFFFFFFFFu) { r0 = r1 = 0; return; }
+  r1 = G;
+  for (uint32_t k = q + 1; k < nq; ++k) {
+    const uint32_t x = qstart[k];
+    if (x != 0xFFFFFFFFu) { r1 = x; break; }
+  }
 }
 
 // one workgroup per query: top-n groups by (count desc, sid asc) over the packed group summaries
-__global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
-                                                     uint32_t nr, m_bits mb, const uint64_t* __restrict__ g_pack,
+__global__ __launch_bounds__(256) void m_topn_kernel(const uint32_t* __restrict__ qstart, uint32_t G, m_bits mb,
+                                                     const uint64_t* __restrict__ g_pack,
                                                      const uint32_t* __restrict__ g_delta,
                                                      const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
                                                      uint32_t* __restrict__ out_sid, int32_t* __restrict__ out_delta,
@@ -965,13 +1126,8 @@ __global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict_
   const uint32_t q = blockIdx.x;
   if (q >= nq) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qshift = mb.sb + mb.dbits + 1;
-  auto lb = [&](uint64_t target) {  // first run whose query index >= target
-    uint32_t l = 0, h = nr;
-    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if ((v[rs[mid]] >> qshift) < target) l = mid + 1; else h = mid; }
-    return l;
-  };
-  const uint32_t r0 = lb(q), r1 = lb((uint64_t)q + 1);
+  uint32_t r0, r1;
+  m_query_groups(qstart, nq, G, q, r0, r1);
   uint64_t prev = ~0ull;  // packed rank of the previous winner; candidates must rank strictly below it
   uint32_t found = 0;
   for (uint32_t n = 0; n < topn; ++n) {
@@ -1010,7 +1166,7 @@ __global__ __launch_bounds__(256) void m_topn_kernel(const uint64_t* __restrict_
 
 // Two-level form of m_topn_kernel for queries with millions of (query, song) groups (a 1M-song table yields ~9M per
 // 10 s query, and only a few dozen queries fit one vote pass): with one workgroup per query the scan of g_pack ran on
-// a few dozen workgroups.  Level 1: workgroup (c, q) finds the top-n of slice c of query q's runs; level 2: one
+// a few dozen workgroups.  Level 1: workgroup (c, q) finds the top-n of slice c of query q's groups; level 2: one
 // workgroup per query ranks the C x topn candidates.  g_pack is unique per group, so "strictly below the previous
 // winner" selects the same groups as the single-level kernel.
 __device__ __forceinline__ void topn_block_max(uint64_t& best, uint32_t& bestr, uint64_t* s_best, uint32_t* s_r) {
@@ -1030,20 +1186,14 @@ __device__ __forceinline__ void topn_block_max(uint64_t& best, uint32_t& bestr, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void m_topn_partial_kernel(const uint64_t* __restrict__ v, const uint32_t* __restrict__ rs,
-                                                             uint32_t nr, m_bits mb, const uint64_t* __restrict__ g_pack,
-                                                             uint32_t topn, uint64_t* __restrict__ part_pack,
+__global__ __launch_bounds__(256) void m_topn_partial_kernel(const uint32_t* __restrict__ qstart, uint32_t G, uint32_t nq,
+                                                             const uint64_t* __restrict__ g_pack, uint32_t topn, uint64_t* __restrict__ part_pack,
                                                              uint32_t* __restrict__ part_r) {
   __shared__ uint64_t s_best[4];
   __shared__ uint32_t s_r[4];
   const uint32_t q = blockIdx.y, c = blockIdx.x, C = gridDim.x;
-  const int qshift = mb.sb + mb.dbits + 1;
-  auto lb = [&](uint64_t target) {
-    uint32_t l = 0, h = nr;
-    while (l < h) { uint32_t mid = l + ((h - l) >> 1); if ((v[rs[mid]] >> qshift) < target) l = mid + 1; else h = mid; }
-    return l;
-  };
-  const uint32_t r0 = lb(q), r1 = lb((uint64_t)q + 1);
+  uint32_t r0, r1;
+  m_query_groups(qstart, nq, G, q, r0, r1);
   const uint32_t S = (r1 - r0 + C - 1) / C;
   const uint32_t a = r0 + (uint32_t)min((uint64_t)c * S, (uint64_t)(r1 - r0));
   const uint32_t b = (uint32_t)min((uint64_t)a + S, (uint64_t)r1);
@@ -1112,42 +1262,42 @@ struct pair_sink {
   uint32_t shard, nshards;  // nshards > 1: only the query hashes this shard owns are looked up
 };
 
-// sort the packed votes, run-length them, fold every (query, sid) group and pick the top-n per query into device
+// sort the packed votes, fold every (query, sid) group into one record and pick the top-n per query into device
 // result arrays (r_*: nq*topn / nq entries, zeroed by the caller).  v0 holds the P votes, v1 is scratch of the same size.
 static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
                          uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
   int sel = 0;
   SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
   const uint64_t* vs = sel ? v1 : v0;
-  uint64_t* other = sel ? v0 : v1;  // free pair buffer: reuse for flags/positions (P*8 bytes = 2 x P u32)
-  uint32_t* rfl = (uint32_t*)other;
-  uint32_t* rps = rfl + P;
-  hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, vs, P, 0, rfl);
-  SHZ_TRY(shz_scan_u32(ctx, rfl, rps, P, d_tot));
-  uint64_t nr64 = 0;
-  SHZ_HIP(ctx, hipMemcpyAsync(&nr64, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  // group heads per wave -> first record slot of every wave -> one record per (query, sid) group
+  const uint32_t nb = nblk((P + RG_PER - 1) / RG_PER), nw = nb * 4;
+  void *wc, *gh, *gd, *gdd;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, ((uint64_t)nw * 2 + nq) * 4, &wc));
+  uint32_t *wcnt = (uint32_t*)wc, *wbase = wcnt + nw, *qstart = wbase + nw;
+  hipLaunchKernelGGL(m_gcount_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb.dbits + 1, wcnt);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));
+  uint64_t G64 = 0;
+  SHZ_HIP(ctx, hipMemcpyAsync(&G64, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(qstart, 0xFF, (uint64_t)nq * 4, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t nr = (uint32_t)nr64;
-  void *rs, *gh, *gd, *gdd;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, (uint64_t)(nr + 1) * 4, &rs));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)nr * 8, &gh));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)nr * 4, &gd));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)nr * 4, &gdd));
-  hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint32_t*)rfl, (const uint32_t*)rps,
-                     P, (const uint64_t*)d_tot, (uint32_t*)rs);
-  hipLaunchKernelGGL(m_group_kernel, dim3(nblk(nr)), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (uint64_t*)gh,
-                     (uint32_t*)gd, (uint32_t*)gdd);
-  // runs per query decide the shape: one workgroup per query, or C slices per query and a final ranking
-  const uint32_t C = (uint32_t)std::min<uint64_t>(512, ((uint64_t)nr / nq + 16383) / 16384);
+  const uint32_t G = (uint32_t)G64;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)G * 8, &gh));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)G * 4, &gd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)G * 4, &gdd));
+  hipLaunchKernelGGL(m_reduce_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb, (const uint32_t*)wbase, (uint64_t*)gh,
+                     (uint32_t*)gd, (uint32_t*)gdd, qstart);
+  // groups per query decide the shape: one workgroup per query, or C slices per query and a final ranking
+  const uint32_t C = (uint32_t)std::min<uint64_t>(512, ((uint64_t)G / nq + 16383) / 16384);
   if (C <= 1) {
-    hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb, (const uint64_t*)gh,
+    hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, G, mb, (const uint64_t*)gh,
                        (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
   } else {
     void *pp, *pr;
     const uint64_t ncand = (uint64_t)C * topn;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)nq * ncand * 8, &pp));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nq * ncand * 4, &pr));
-    hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, vs, (const uint32_t*)rs, nr, mb,
+    hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, G, nq,
                        (const uint64_t*)gh, topn, (uint64_t*)pp, (uint32_t*)pr);
     hipLaunchKernelGGL(m_topn_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint64_t*)pp, (const uint32_t*)pr,
                        (uint32_t)ncand, mb, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
@@ -1265,7 +1415,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
     }
     // groups = distinct (query, key)
-    void *gs, *glo, *grows, *gpairs, *po;
+    void *gs, *glo, *gpairs, *po;
     hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint64_t*)E, mu, QKEY_SHIFT,
                        (uint32_t*)fl);
     SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, mu, (uint64_t*)tot + 1));
@@ -1273,18 +1423,22 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_HIP(ctx, hipMemcpyAsync(&ng64, (uint64_t*)tot + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t ng = (uint32_t)ng64;
+    const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
+    if (nx >= (1ull << 32)) {
+      if (nq > 1) { step = nq / 2; continue; }
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u: %u distinct hashes x %d segments", q0, ng, nseg);
+    }
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)(ng + 1) * 4, &gs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)(ng + 1) * 4 * nseg, &glo));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)(ng + 1) * 4 * nseg, &grows));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)(ng + 1) * 8, &gpairs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, (uint64_t)(ng + 1) * 8, &po));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (nx + 1) * 4, &glo));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (nx + 1) * 8, &gpairs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, (nx + 1) * 8, &po));
     hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
                        (const uint32_t*)ps, mu, (const uint64_t*)tot + 1, (uint32_t*)gs);
-    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk((uint64_t)ng + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
-                       (const uint32_t*)gs, ng, (const shz_seg_dev*)d_segs, nseg, (uint32_t*)glo, (uint32_t*)grows,
+    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                       (const uint32_t*)gs, ng, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
                        (uint64_t*)gpairs, (unsigned long long*)tot + 2);
     SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, (uint64_t)ng + 1, (uint64_t*)tot + 3));
+    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx + 1, (uint64_t*)tot + 3));
     uint64_t P = 0, rows_total = 0;
     SHZ_HIP(ctx, hipMemcpyAsync(&P, (uint64_t*)tot + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipMemcpyAsync(&rows_total, (uint64_t*)tot + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1302,7 +1456,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)nq * 4, &d_nh));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)nq * 8, &d_np));
     hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
-                       (const uint32_t*)gs, ng, (const uint64_t*)po, nq, (uint32_t*)d_nh, (uint64_t*)d_np);
+                       (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, (uint32_t*)d_nh, (uint64_t*)d_np);
     SHZ_HIP(ctx, hipGetLastError());
     if (out_nhash) SHZ_HIP(ctx, hipMemcpyAsync(out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_npairs) SHZ_HIP(ctx, hipMemcpyAsync(out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1324,9 +1478,9 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     if (P > 0 && vs_out) {
       // hand the votes over: expand straight into the caller's buffer, in the shared layout, with global query indices
       if (vs_out->count + P <= vs_out->cap) {
-        hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                           ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)grows, (const shz_seg_dev*)d_segs,
-                           nseg, P, vs_out->lay, q0, vs_out->d_pairs + vs_out->count);
+        hipLaunchKernelGGL(m_expand_kernel, dim3((unsigned)((P + M_EXP_TILE - 1) / M_EXP_TILE)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                           (uint32_t)nx, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
+                           (uint32_t)nseg, P, vs_out->lay, q0, vs_out->d_pairs + vs_out->count);
         SHZ_HIP(ctx, hipGetLastError());
       }
       vs_out->count += P;  // keeps counting past cap: the caller learns the size it needs
@@ -1335,9 +1489,9 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       void *v0, *v1;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
-      hipLaunchKernelGGL(m_expand_kernel, dim3(nblk(P)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                         ng, (const uint64_t*)po, (const uint32_t*)glo, (const uint32_t*)grows, (const shz_seg_dev*)d_segs,
-                         nseg, P, mb, 0u, (uint64_t*)v0);
+      hipLaunchKernelGGL(m_expand_kernel, dim3((unsigned)((P + M_EXP_TILE - 1) / M_EXP_TILE)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                         (uint32_t)nx, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
+                         (uint32_t)nseg, P, mb, 0u, (uint64_t*)v0);
       SHZ_HIP(ctx, hipGetLastError());
       SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, (uint64_t*)tot + 4, (uint32_t*)r_sid,
                         (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
