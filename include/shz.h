@@ -238,8 +238,8 @@ int32_t shz_match_pairs(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const
 /* all-gather the ranks' votes (device in, device buffer of cap entries out) */
 int32_t shz_pairs_allgather(shz_comm* c, uint64_t n_local, const uint64_t* d_pairs, uint64_t* d_all, uint64_t cap,
                             uint64_t* n_total);
-/* the tail of shz_match_batch over any collection of votes in that layout: sort, run lengths, per (query, song)
- * fold, top-n ranked like align_matches (recognizer.py:289-338).  d_pairs (device) is overwritten.  n < 2^32.
+/* the tail of shz_match_batch over any collection of votes in that layout: sort, per (query, song) fold, top-n
+ * ranked like align_matches (recognizer.py:289-338).  d_pairs (device, 16-byte aligned) is overwritten.  n < 2^32.
  * Outputs (host) as in shz_match_batch. */
 int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, uint32_t n_queries, uint32_t sid_bits,
                        uint32_t delta_bits, uint32_t bias, uint32_t topn, uint32_t* out_sid, int32_t* out_delta,

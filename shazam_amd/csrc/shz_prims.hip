@@ -148,16 +148,20 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 }
 
 // ---------------------------------------------------------------------------------------
-// Stable LSD radix sort, 8 bits per pass.  Tile = 4096 keys per workgroup of 256 threads.
+// Stable LSD radix sort, 8 or 9 bits per pass (9 only where it saves a whole pass: e.g. 35 key bits = 9+9+9+8).
+// Tile = 4096 keys per workgroup of 256 threads.
 #define SORT_THREADS 256
 #define SORT_ROUNDS 16
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
 
+template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
-                                                                  uint32_t* __restrict__ hist /*[256][nblocks]*/,
+                                                                  uint32_t* __restrict__ hist /*[2^BITS][nblocks]*/,
                                                                   uint32_t nblocks) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  constexpr uint32_t DIG = 1u << BITS;
+  __shared__ uint32_t h[DIG];
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
   if (base + SORT_TILE <= n) {  // whole tile: all loads in flight (two keys per lane and load) before the first count
@@ -167,17 +171,18 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) x[r] = k2[r * SORT_THREADS + threadIdx.x];
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) {
-      atomicAdd(&h[(x[r].x >> shift) & 255u], 1u);
-      atomicAdd(&h[(x[r].y >> shift) & 255u], 1u);
+      atomicAdd(&h[(x[r].x >> shift) & (DIG - 1)], 1u);
+      atomicAdd(&h[(x[r].y >> shift) & (DIG - 1)], 1u);
     }
   } else {
     for (int r = 0; r < SORT_ROUNDS; ++r) {
       uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
-      if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+      if (i < n) atomicAdd(&h[(keys[i] >> shift) & (DIG - 1)], 1u);
     }
   }
   __syncthreads();
-  hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 template <int VB> struct val_t { typedef uint32_t type; };
@@ -189,21 +194,23 @@ template <> struct val_t<8> { typedef uint64_t type; };
 // covers the tile); a key's slot = first slot of its digit + keys of that digit in earlier waves + its rank among the
 // wave's own keys of that digit (ballot rank inside a row + the wave's running count, which only that wave touches:
 // LDS operations of one wave execute in order, so the rows need no barrier).
-template <int VB>
+template <int VB, int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys,
                                                                      const void* __restrict__ vals_,
                                                                      uint64_t* __restrict__ okeys,
                                                                      void* __restrict__ ovals_, uint64_t n, int shift,
-                                                                     const uint32_t* __restrict__ offs /*[256][nblocks]*/,
+                                                                     const uint32_t* __restrict__ offs /*[2^BITS][nblocks]*/,
                                                                      uint32_t nblocks) {
   typedef typename val_t<VB>::type V;
+  constexpr uint32_t DIG = 1u << BITS;
+  constexpr int DPT = DIG / SORT_THREADS;   // digits per thread in the bookkeeping steps: thread t owns t*DPT ...
   const V* vals = (const V*)vals_;
   V* ovals = (V*)ovals_;
   __shared__ uint64_t skey[SORT_TILE];
   __shared__ V sval[VB ? SORT_TILE : 1];
-  __shared__ uint32_t lstart[256];       // first LDS slot of each digit's run
-  __shared__ uint32_t gbase[256];        // first global slot of each digit's run of this tile
-  __shared__ uint32_t wrun[4][256];      // per wave: running digit counts, then the first slot of the wave's keys per digit
+  __shared__ uint32_t gbase[DIG];        // first global slot of each digit's run of this tile
+  __shared__ uint16_t lstart[DIG];       // first LDS slot of each digit's run (all LDS slots < 4096)
+  __shared__ uint16_t wrun[4][DIG];      // per wave: running digit counts, then the first slot of the wave's keys per digit
   __shared__ uint32_t scan_tmp[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
@@ -218,15 +225,27 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
     if (VB != 0) pv[r] = li < tile_n ? vals[base + li] : 0;
   }
 #pragma unroll
-  for (int w = 0; w < 4; ++w) wrun[w][threadIdx.x] = 0;
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) wrun[w][threadIdx.x * DPT + i] = 0;
   {  // digit counts of this tile from the scanned histogram: next flattened entry minus this one
-    const uint64_t f = (uint64_t)threadIdx.x * nblocks + blockIdx.x;
-    const uint32_t g0 = offs[f];
-    const uint32_t g1 = (f + 1 < (uint64_t)256 * nblocks) ? offs[f + 1] : (uint32_t)n;
+    uint32_t g0[DPT], c[DPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const uint64_t f = (uint64_t)(threadIdx.x * DPT + i) * nblocks + blockIdx.x;
+      g0[i] = offs[f];
+      const uint32_t g1 = (f + 1 < (uint64_t)DIG * nblocks) ? offs[f + 1] : (uint32_t)n;
+      c[i] = g1 - g0[i];
+      sum += c[i];
+    }
     uint32_t tot;
-    const uint32_t ls = block_excl_scan<uint32_t>(g1 - g0, &tot, scan_tmp);
-    gbase[threadIdx.x] = g0;
-    lstart[threadIdx.x] = ls;
+    uint32_t ls = block_excl_scan<uint32_t>(sum, &tot, scan_tmp);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      gbase[threadIdx.x * DPT + i] = g0[i];
+      lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
+      ls += c[i];
+    }
   }
   __syncthreads();
   uint32_t rank[ROWS];
@@ -235,33 +254,35 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
-    const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & (DIG - 1);
     unsigned long long peers = __ballot(valid);   // valid lanes of this row holding the same digit
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
     const uint32_t rk = (uint32_t)__popcll(peers & lt);
     const uint32_t run = wrun[wave][d];
     rank[r] = run + rk;
-    if (valid && rk == 0) wrun[wave][d] = run + (uint32_t)__popcll(peers);
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
   }
   __syncthreads();
-  {
-    const uint32_t c0 = wrun[0][threadIdx.x], c1 = wrun[1][threadIdx.x], c2 = wrun[2][threadIdx.x];
-    const uint32_t ls = lstart[threadIdx.x];
-    wrun[0][threadIdx.x] = ls;
-    wrun[1][threadIdx.x] = ls + c0;
-    wrun[2][threadIdx.x] = ls + c0 + c1;
-    wrun[3][threadIdx.x] = ls + c0 + c1 + c2;
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) {
+    const uint32_t d = threadIdx.x * DPT + i;
+    const uint32_t c0 = wrun[0][d], c1 = wrun[1][d], c2 = wrun[2][d];
+    const uint32_t ls = lstart[d];
+    wrun[0][d] = (uint16_t)ls;
+    wrun[1][d] = (uint16_t)(ls + c0);
+    wrun[2][d] = (uint16_t)(ls + c0 + c1);
+    wrun[3][d] = (uint16_t)(ls + c0 + c1 + c2);
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     if (li < tile_n) {
-      const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+      const uint32_t d = (uint32_t)(k[r] >> shift) & (DIG - 1);
       const uint32_t pos = wrun[wave][d] + rank[r];
       skey[pos] = k[r];
       if (VB != 0) sval[pos] = pv[r];
@@ -270,11 +291,29 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
     const uint64_t kk = skey[i];
-    const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+    const uint32_t d = (uint32_t)(kk >> shift) & (DIG - 1);
     const uint32_t g = gbase[d] + (i - lstart[d]);
     okeys[g] = kk;
     if (VB != 0) ovals[g] = sval[i];
   }
+}
+
+template <int BITS>
+static int32_t sort_pass(shz_ctx* ctx, uint32_t nblocks, const uint64_t* kin, const void* vin, uint64_t* kout, void* vout,
+                      int vbytes, uint64_t n, int shift, uint32_t* hist) {
+  hipLaunchKernelGGL(sort_hist_kernel<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, n, shift, hist, nblocks);
+  SHZ_TRY(shz_scan_u32(ctx, hist, hist, (uint64_t)nblocks << BITS, nullptr));
+  if (vbytes == 4)
+    hipLaunchKernelGGL((sort_scatter_kernel<4, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                       n, shift, (const uint32_t*)hist, nblocks);
+  else if (vbytes == 8)
+    hipLaunchKernelGGL((sort_scatter_kernel<8, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                       n, shift, (const uint32_t*)hist, nblocks);
+  else
+    hipLaunchKernelGGL((sort_scatter_kernel<0, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                       n, shift, (const uint32_t*)hist, nblocks);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
 }
 
 int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, uint64_t n, int bit_lo,
@@ -284,28 +323,23 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
   if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: n must be < 2^32 (got %llu)", (unsigned long long)n);
   if (vbytes != 0 && vbytes != 4 && vbytes != 8) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: payload must be 0, 4 or 8 bytes");
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+  const int bits = bit_hi - bit_lo;
+  const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
+  const bool wide = np9 < np8;   // 9-bit digits only where they save a pass
   void* hist;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, (uint64_t)nblocks * 256 * 4, &hist));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, ((uint64_t)nblocks << (wide ? 9 : 8)) * 4, &hist));
   uint64_t* kin = k0;
   uint64_t* kout = k1;
   void* vin = v0;
   void* vout = v1;
-  int sel = 0;
-  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, n, shift,
-                       (uint32_t*)hist, nblocks);
-    SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, (uint64_t)nblocks * 256, nullptr));
-    if (vbytes == 4)
-      hipLaunchKernelGGL(sort_scatter_kernel<4>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
-                         vout, n, shift, (const uint32_t*)hist, nblocks);
-    else if (vbytes == 8)
-      hipLaunchKernelGGL(sort_scatter_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
-                         vout, n, shift, (const uint32_t*)hist, nblocks);
+  int sel = 0, left = wide ? np9 : np8;
+  for (int shift = bit_lo; shift < bit_hi; --left) {
+    const int w = wide ? (bit_hi - shift + left - 1) / left : 8;   // wide: spread the bits evenly, each digit <= 9
+    if (w == 9)
+      SHZ_TRY(sort_pass<9>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, (uint32_t*)hist));
     else
-      hipLaunchKernelGGL(sort_scatter_kernel<0>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout,
-                         vout, n, shift, (const uint32_t*)hist, nblocks);
-    SHZ_HIP(ctx, hipGetLastError());
+      SHZ_TRY(sort_pass<8>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, (uint32_t*)hist));
+    shift += w == 9 ? 9 : 8;
     uint64_t* tk = kin; kin = kout; kout = tk;
     void* tv = vin; vin = vout; vout = tv;
     sel ^= 1;

@@ -555,11 +555,18 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
       if (sl + 1 < nsl) freeze_active(t);
     }
   }
-  void* st[] = {t->skey, t->ssid, t->soff};
-  for (void* p : st)
-    if (p) SHZ_HIP(ctx, hipFree(p));
-  t->skey = t->ssid = t->soff = nullptr;
-  t->ns = t->scap = 0;
+  // The staging columns stay allocated for the next batch (a stream of ingest batches otherwise pays three
+  // hipMalloc + growth copies per batch) unless they hold more than a quarter of what is free now.
+  size_t mem_free = 0, mem_total = 0;
+  SHZ_HIP(ctx, hipMemGetInfo(&mem_free, &mem_total));
+  if (t->scap * 12 > mem_free / 4) {
+    void* st[] = {t->skey, t->ssid, t->soff};
+    for (void* p : st)
+      if (p) SHZ_HIP(ctx, hipFree(p));
+    t->skey = t->ssid = t->soff = nullptr;
+    t->scap = 0;
+  }
+  t->ns = 0;
   return SHZ_OK;
 }
 
@@ -885,83 +892,111 @@ __global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu
 
 struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset of the sub-batch: delta + bias >= 0
 
-// last g in [0, ng) with po[g] <= p, by the 64 lanes of one wave (po is ascending, po[0] = 0): 64-ary steps
-__device__ __forceinline__ uint32_t m_wave_search(const uint64_t* __restrict__ po, uint32_t ng, uint64_t p) {
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t lo = 0, n = ng;
-  while (n > 1) {
-    const uint32_t step = (n + 63) / 64;
-    const uint32_t idx = lo + lane * step;
-    const bool ok = lane * step < n && po[idx] <= p;   // a prefix of the lanes (lane 0 always)
-    const unsigned long long b = __ballot(ok);
-    const uint32_t last = 63u - (uint32_t)__clzll(b);
-    n = min(step, n - last * step);
-    lo += last * step;
-  }
-  return lo;
-}
-
 // expand: pair p = (query hash element, table row) of sub-group x = (group g, segment sg), packed as a vote.  A
-// workgroup owns M_EXP_TILE consecutive pairs: two waves find the sub-groups of its first and last pair, every thread
-// then searches only between them (a tile spans a handful of sub-groups, the whole po[] has ~1e6 entries), all of a
-// thread's pairs in lockstep so that their loads overlap.
+// workgroup owns M_EXP_TILE consecutive pairs.  m_tile_start_kernel finds the sub-group of every tile's first pair; a
+// tile spans a handful of sub-groups (the whole po[] has ~1e6 entries), so the workgroup copies their descriptors to
+// LDS once and every pair is resolved from there: the only per-pair global traffic is the table row and the store.
 #define M_EXP_PER 8
 #define M_EXP_TILE (256 * M_EXP_PER)
+#define M_EXP_SUB 512   // sub-groups per tile that fit the LDS tables (more: the same search over global memory)
+
+// tile_x[t] = last x in [0, nx) with po[x] <= min(t * M_EXP_TILE, P - 1), t = 0 .. ntiles
+__global__ void m_tile_start_kernel(const uint64_t* __restrict__ po, uint32_t nx, uint64_t P, uint32_t ntiles,
+                                    uint32_t* __restrict__ tile_x) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  const uint64_t p = min((uint64_t)t * M_EXP_TILE, P - 1);
+  uint32_t l = 0, h = nx;
+  while (h - l > 1) {
+    const uint32_t mid = l + ((h - l) >> 1);
+    if (po[mid] <= p) l = mid; else h = mid;
+  }
+  tile_x[t] = l;
+}
+
+__device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t off, uint32_t first, m_bits mb, uint32_t q_base) {
+  const uint64_t q = (e >> QIDX_SHIFT) + q_base;
+  const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
+  const uint64_t dprime = (uint64_t)off + mb.bias - qo;  // delta + bias >= 0
+  return ((((q << mb.sb) | sid) << mb.dbits | dprime) << 1) | first;
+}
+
 __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
-                                                       uint32_t nx, const uint64_t* __restrict__ po,
+                                                       const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
                                                        const uint32_t* __restrict__ g_lo,
                                                        const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t P,
                                                        m_bits mb, uint32_t q_base, uint64_t* __restrict__ v) {
-  __shared__ uint32_t s_x[2];
+  __shared__ uint64_t s_po[M_EXP_SUB], s_e[M_EXP_SUB];
+  __shared__ uint32_t s_lo[M_EXP_SUB], s_e0[M_EXP_SUB], s_noff[M_EXP_SUB], s_sg[M_EXP_SUB];
+  __shared__ const uint32_t* s_sid[SHZ_MAX_SEGS];
+  __shared__ const uint32_t* s_off[SHZ_MAX_SEGS];
   const uint64_t base = (uint64_t)blockIdx.x * M_EXP_TILE;
   const uint64_t last = min(base + M_EXP_TILE, P) - 1;
-  const int wave = threadIdx.x >> 6;
-  if (wave < 2) {
-    const uint32_t x = m_wave_search(po, nx, wave ? last : base);
-    if ((threadIdx.x & 63) == 0) s_x[wave] = x;
-  }
-  __syncthreads();
-  const uint32_t xA = s_x[0], xB = s_x[1];
+  const uint32_t xA = tile_x[blockIdx.x], xB = tile_x[blockIdx.x + 1];  // sub-groups of the tile's pairs: [xA, xB]
+  const uint32_t cnt = xB - xA + 1;
   int iters = 0;
-  while ((1u << iters) < xB - xA + 1) ++iters;  // uniform
+  while ((1u << iters) < cnt) ++iters;  // uniform
   uint64_t p[M_EXP_PER];
   uint32_t l[M_EXP_PER], h[M_EXP_PER];
 #pragma unroll
-  for (int j = 0; j < M_EXP_PER; ++j) {
+  for (int j = 0; j < M_EXP_PER; ++j)
     p[j] = min(base + (uint64_t)j * 256 + threadIdx.x, last);  // clamped: lanes past the end redo the last pair, unstored
-    l[j] = xA;
-    h[j] = xB + 1;  // last x in [xA, xB] with po[x] <= p
+  if (threadIdx.x < nseg) { s_sid[threadIdx.x] = segs[threadIdx.x].sid; s_off[threadIdx.x] = segs[threadIdx.x].off; }
+  if (cnt <= M_EXP_SUB) {  // uniform
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+      const uint32_t x = xA + i, g = x / nseg;
+      const uint32_t e0 = gs[g];
+      s_po[i] = po[x];
+      s_lo[i] = g_lo[x];
+      s_e0[i] = e0;
+      s_noff[i] = gs[g + 1] - e0;
+      s_sg[i] = x - g * nseg;
+      s_e[i] = E[e0];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < M_EXP_PER; ++j) { l[j] = 0; h[j] = cnt; }  // last i in [0, cnt) with s_po[i] <= p
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < M_EXP_PER; ++j) {
+        const uint32_t mid = (l[j] + h[j]) >> 1;   // == l once h - l <= 1: s_po[l] <= p keeps l
+        if (s_po[mid] <= p[j]) l[j] = mid; else h[j] = mid;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < M_EXP_PER; ++j) {
+      const uint32_t i = l[j];
+      const uint32_t noff = s_noff[i];
+      const uint32_t r = (uint32_t)(p[j] - s_po[i]);  // < P < 2^32
+      uint32_t ridx = r, oi = 0;                      // row number inside the sub-group's rows, offset of the hash
+      uint64_t e = s_e[i];
+      if (noff != 1) { ridx = r / noff; oi = r - ridx * noff; e = E[s_e0[i] + oi]; }
+      const uint32_t row = s_lo[i] + ridx, sg = s_sg[i];
+      const uint64_t out = m_vote(e, s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
+      const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
+      if (pj < P) v[pj] = out;
+    }
+    return;
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < M_EXP_PER; ++j) { l[j] = xA; h[j] = xB + 1; }  // last x in [xA, xB] with po[x] <= p
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < M_EXP_PER; ++j) {
-      const uint32_t mid = (l[j] + h[j]) >> 1;   // == l once h - l <= 1: po[l] <= p keeps l
+      const uint32_t mid = (l[j] + h[j]) >> 1;
       if (po[mid] <= p[j]) l[j] = mid; else h[j] = mid;
     }
   }
-  uint32_t row[M_EXP_PER], sg[M_EXP_PER], flag[M_EXP_PER];
-  uint64_t e[M_EXP_PER];
-#pragma unroll
+#pragma unroll 2
   for (int j = 0; j < M_EXP_PER; ++j) {
-    const uint32_t x = l[j];
-    const uint32_t g = x / nseg;
-    sg[j] = x - g * nseg;
+    const uint32_t x = l[j], g = x / nseg, sg = x - g * nseg;
     const uint32_t e0 = gs[g], noff = gs[g + 1] - e0;
-    const uint32_t r = (uint32_t)(p[j] - po[x]);  // < P < 2^32
-    uint32_t ridx = r, oi = 0;                    // row number inside the sub-group's rows, offset of the hash
+    const uint32_t r = (uint32_t)(p[j] - po[x]);
+    uint32_t ridx = r, oi = 0;
     if (noff != 1) { ridx = r / noff; oi = r - ridx * noff; }
-    row[j] = g_lo[x] + ridx;
-    e[j] = E[e0 + oi];
-    flag[j] = oi == 0 ? 1u : 0u;
-  }
-#pragma unroll
-  for (int j = 0; j < M_EXP_PER; ++j) {
-    const uint32_t* __restrict__ tsid = segs[sg[j]].sid;
-    const uint32_t* __restrict__ toff = segs[sg[j]].off;
-    const uint64_t q = (e[j] >> QIDX_SHIFT) + q_base;
-    const uint32_t qo = (uint32_t)e[j] & ((1u << QOFF_BITS) - 1);
-    const uint64_t dprime = (uint64_t)toff[row[j]] + mb.bias - qo;  // delta + bias >= 0
-    const uint64_t out = ((((q << mb.sb) | tsid[row[j]]) << mb.dbits | dprime) << 1) | flag[j];
+    const uint32_t row = g_lo[x] + ridx;
+    const uint64_t out = m_vote(E[e0 + oi], s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
     const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
     if (pj < P) v[pj] = out;
   }
@@ -1267,7 +1302,8 @@ struct pair_sink {
 static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
                          uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
   int sel = 0;
-  SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 0, mb.qb + mb.sb + mb.dbits + 1, &sel));
+  // bit 0 (the first-offset flag) is only counted by the fold, never compared: it stays out of the sort
+  SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
   const uint64_t* vs = sel ? v1 : v0;
   // group heads per wave -> first record slot of every wave -> one record per (query, sid) group
   const uint32_t nb = nblk((P + RG_PER - 1) / RG_PER), nw = nb * 4;
@@ -1475,11 +1511,18 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
       SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
     }
+    const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
+    void* tile_x = nullptr;
+    if (P > 0 && (!vs_out || vs_out->count + P <= vs_out->cap)) {
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, ((uint64_t)ntiles + 1) * 4, &tile_x));
+      hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)po,
+                         (uint32_t)nx, P, ntiles, (uint32_t*)tile_x);
+    }
     if (P > 0 && vs_out) {
       // hand the votes over: expand straight into the caller's buffer, in the shared layout, with global query indices
       if (vs_out->count + P <= vs_out->cap) {
-        hipLaunchKernelGGL(m_expand_kernel, dim3((unsigned)((P + M_EXP_TILE - 1) / M_EXP_TILE)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                           (uint32_t)nx, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
+        hipLaunchKernelGGL(m_expand_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                           (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
                            (uint32_t)nseg, P, vs_out->lay, q0, vs_out->d_pairs + vs_out->count);
         SHZ_HIP(ctx, hipGetLastError());
       }
@@ -1489,8 +1532,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       void *v0, *v1;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
-      hipLaunchKernelGGL(m_expand_kernel, dim3((unsigned)((P + M_EXP_TILE - 1) / M_EXP_TILE)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                         (uint32_t)nx, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
+      hipLaunchKernelGGL(m_expand_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
+                         (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
                          (uint32_t)nseg, P, mb, 0u, (uint64_t*)v0);
       SHZ_HIP(ctx, hipGetLastError());
       SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, (uint64_t*)tot + 4, (uint32_t*)r_sid,
@@ -1769,6 +1812,7 @@ extern "C" int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, u
   memset(out_dedup, 0, nres * 4); memset(out_nres, 0, (uint64_t)n_queries * 4);
   if (n == 0) return SHZ_OK;
   if (!d_pairs) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_pairs_vote: NULL votes");
+  if ((uintptr_t)d_pairs & 15) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_pairs_vote: the vote buffer must be 16-byte aligned");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void *v1, *tot, *r_sid, *r_delta, *r_al, *r_dd, *r_n;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * 8, &v1));
