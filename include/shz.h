@@ -89,6 +89,12 @@ int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_cl
  * freed inside; gb_per_s = bytes moved / hipEvent time over `iters` launches (16 B per lane, grid-stride). */
 int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s);
 
+/* The device radix sort the table build and the vote use (tests / tools): stable sort of n 64-bit keys on bits
+ * [bit_lo, bit_hi) -- rounded up to whole digits of 8 or 9 bits --, carrying a payload of val_bytes = 0, 4 or 8
+ * bytes per key.  keys / vals are HOST arrays, sorted in place.  n < 2^32. */
+int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_bytes, uint64_t n, uint32_t bit_lo,
+                       uint32_t bit_hi);
+
 /* Query preparation (bench / tests): exact sum of squares of each clip (device PCM, clip-major, equal
  * lengths) to HOST, and out = clip(rint(sig + scale[c] * noise)) on the device: the digital form of
  * get_noise_from_sound + sf.write (recognizer_test.py:426-435, 557); twin: oracle/synth.mix_query. */

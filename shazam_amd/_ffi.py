@@ -40,6 +40,7 @@ SIGNATURES = {
     "shz_sumsq_i16": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint64, u64p]),
     "shz_mix_i16": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, f64p, vp]),
     "shz_membw": (C.c_int32, [vp, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
+    "shz_sort_pairs": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -194,6 +195,20 @@ class Context:
         g = C.c_float()
         self.check(lib().shz_membw(self.h, int(mode), int(nbytes), int(iters), C.byref(g)))
         return float(g.value)
+
+    def sort_pairs(self, keys: np.ndarray, vals=None, bit_lo: int = 0, bit_hi: int = 64):
+        """Stable device radix sort of uint64 keys on bits [bit_lo, bit_hi) (whole 8/9-bit digits), with an optional
+        uint32 / uint64 payload; returns sorted copies."""
+        k = np.ascontiguousarray(keys, np.uint64).copy()
+        v, vb = None, 0
+        if vals is not None:
+            v = np.ascontiguousarray(vals).copy()
+            vb = v.dtype.itemsize
+            if vb not in (4, 8) or v.shape != k.shape:
+                raise ValueError("payload must be 4 or 8 bytes per key")
+        self.check(lib().shz_sort_pairs(self.h, k.ctypes.data, v.ctypes.data if v is not None else None, vb, k.size,
+                                        int(bit_lo), int(bit_hi)))
+        return (k, v) if v is not None else k
 
     def set_workspace_limit(self, nbytes):
         self.check(lib().shz_set_workspace_limit(self.h, int(nbytes)))

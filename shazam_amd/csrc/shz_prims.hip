@@ -347,3 +347,27 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
   *out_sel = sel;
   return SHZ_OK;
 }
+
+extern "C" int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_bytes, uint64_t n, uint32_t bit_lo,
+                                  uint32_t bit_hi) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (n == 0) return SHZ_OK;
+  if (!keys || (val_bytes && !vals)) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_pairs: NULL buffer");
+  if (bit_hi > 64 || bit_lo > bit_hi) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_pairs: bits [%u, %u)", bit_lo, bit_hi);
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void *k0, *k1, *v0 = nullptr, *v1 = nullptr;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &k1));
+  if (val_bytes) {
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, n * val_bytes, &v0));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * val_bytes, &v1));
+    SHZ_HIP(ctx, hipMemcpyAsync(v0, vals, n * val_bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SHZ_HIP(ctx, hipMemcpyAsync(k0, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  int sel = 0;
+  SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)k0, (uint64_t*)k1, v0, v1, (int)val_bytes, n, (int)bit_lo, (int)bit_hi, &sel));
+  SHZ_HIP(ctx, hipMemcpyAsync(keys, sel ? k1 : k0, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (val_bytes) SHZ_HIP(ctx, hipMemcpyAsync(vals, sel ? v1 : v0, n * val_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}

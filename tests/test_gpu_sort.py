@@ -1,0 +1,55 @@
+"""GPU: the stable LSD radix sort behind the table build and the vote (shz_prims.hip), against numpy's stable
+argsort: 8- and 9-bit digit plans, payloads of 0 / 4 / 8 bytes, partial tiles, tiny inputs, heavy duplicates and
+already-sorted / constant digits (every lane of a row in one bin)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _digits(bit_lo, bit_hi):
+    """bits the device actually sorts on: whole digits, 9 wide only where that saves a pass (see shz_sort_u64)"""
+    bits = bit_hi - bit_lo
+    np8, np9 = (bits + 7) // 8, (bits + 8) // 9
+    if np9 >= np8:
+        return bit_lo, min(64, bit_lo + 8 * np8)
+    return bit_lo, bit_hi   # 9,9,..,8 plans cover the range exactly
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 3 * 4096 + 17, 300001])
+@pytest.mark.parametrize("bits", [(0, 8), (0, 9), (1, 36), (0, 27), (5, 23), (0, 62), (32, 41), (0, 64)])
+@pytest.mark.parametrize("vb", [0, 4, 8])
+def test_sort_matches_stable_argsort(n, bits, vb):
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    if n > 5000 and vb == 4 and bits not in ((1, 36), (0, 62)):
+        pytest.skip("large cases: a subset")
+    rng = np.random.default_rng(n * 131 + bits[1] * 7 + vb)
+    keys = rng.integers(0, 1 << 63, n, dtype=np.uint64) * 2 + rng.integers(0, 2, n, dtype=np.uint64)
+    if n > 100:
+        keys[n // 3: n // 3 + n // 4] = keys[n // 3]                       # a long run of one key
+        keys[-(n // 5):] &= np.uint64(0xFFFF)                              # many small keys: few distinct high digits
+    lo, hi = _digits(*bits)
+    mask = np.uint64(((1 << (hi - lo)) - 1) << lo) if hi - lo < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    order = np.argsort((keys & mask) >> np.uint64(lo), kind="stable")
+    if vb == 0:
+        got = ctx.sort_pairs(keys, None, *bits)
+        assert np.array_equal(got, keys[order])
+    else:
+        vals = np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64) * (3 if vb == 4 else 0x100000001)
+        gk, gv = ctx.sort_pairs(keys, vals, *bits)
+        assert np.array_equal(gk, keys[order])
+        assert np.array_equal(gv, vals[order])       # stability: equal digits keep their input order
+
+
+def test_sorted_and_constant_inputs():
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    n = 50000
+    asc = np.arange(n, dtype=np.uint64) << np.uint64(3)
+    assert np.array_equal(ctx.sort_pairs(asc, None, 0, 20), asc)
+    assert np.array_equal(ctx.sort_pairs(asc[::-1], None, 0, 20), asc)
+    const = np.full(n, 0x1234567, np.uint64)
+    k, v = ctx.sort_pairs(const, np.arange(n, dtype=np.uint32), 0, 35)
+    assert np.array_equal(k, const) and np.array_equal(v, np.arange(n, dtype=np.uint32))
+    assert ctx.sort_pairs(np.zeros(0, np.uint64), None, 0, 64).size == 0
