@@ -73,3 +73,52 @@ def test_segmented_table_equals_single():
         assert got == [tuple(w) for w in want] and int(rb["npairs"][q]) == len(m)
     one.close()
     seg.close()
+
+
+def test_sparse_hits_over_many_segments():
+    """Few matching rows under thousands of empty (hash, segment) sub-groups: one expand tile then spans far more
+    sub-groups than its LDS tables hold (the global-memory branch of m_expand_kernel), with query hashes that occur at
+    several offsets (n_offsets > 1 per group) in both branches."""
+    import shazam_amd as S
+    from oracle import cpu_ref as O
+    ctx = S.get_context(0)
+    rng = np.random.default_rng(31)
+    seg, one, odb = S.Table(ctx), S.Table(ctx), O.DictDB()
+    seg.set_segment_rows(700)
+    for s_ in range(1, 300):
+        odb.insert_song(str(s_), "00", 1)
+    present = []
+    for part in range(18):                                  # 18 finalizes of 600 rows -> ~16 segments
+        key = ((rng.integers(300, 900, 600) << 20) | (rng.integers(0, 2049, 600) << 8) | rng.integers(0, 201, 600)).astype(np.uint32)
+        sid = (rng.integers(1, 17, 600) + 16 * part).astype(np.uint32)
+        off = rng.integers(0, 90, 600).astype(np.uint32)
+        for t in (seg, one):
+            t.insert(key, sid, off)
+        seg.finalize()
+        present.append(key)
+        for kk, ss, oo in zip(key.tolist(), sid.tolist(), off.tolist()):
+            odb.insert_hashes(ss, [(kk, oo)])
+    one.finalize()
+    present = np.concatenate(present)
+    qk, qo, qoff = [], [], [0]
+    for q in range(3):
+        miss = ((rng.integers(0, 290, 3500) << 20) | (rng.integers(0, 2049, 3500) << 8) | rng.integers(0, 201, 3500)).astype(np.uint32)
+        hit = present[rng.integers(0, len(present), 40)]
+        hit = np.concatenate([hit, hit[:15], hit[:5]])      # the same hash at two and three query offsets
+        k = np.concatenate([miss, hit])
+        o = rng.integers(0, 30, len(k)).astype(np.uint32)
+        p = rng.permutation(len(k))
+        qk.append(k[p]); qo.append(o[p]); qoff.append(qoff[-1] + len(k))
+    qk, qo, qoff = np.concatenate(qk), np.concatenate(qo), np.array(qoff, np.uint64)
+    ra, rb = one.match(qk, qo, qoff, 6), seg.match(qk, qo, qoff, 6)
+    for f in ("sid", "delta", "aligned", "dedup", "nres", "nhash", "npairs"):
+        assert np.array_equal(ra[f], rb[f]), f
+    for q in range(3):
+        hs = set(zip(qk[qoff[q]:qoff[q + 1]].tolist(), qo[qoff[q]:qoff[q + 1]].tolist()))
+        m, dd = O.return_matches(hs, odb)
+        want = O.vote(m, 6)
+        got = [(int(rb["sid"][q, i]), int(rb["delta"][q, i]), int(rb["aligned"][q, i])) for i in range(int(rb["nres"][q]))]
+        assert got == [tuple(w) for w in want] and int(rb["npairs"][q]) == len(m) > 40
+        assert [int(rb["dedup"][q, i]) for i in range(len(got))] == [dd[w[0]] for w in want]
+    one.close()
+    seg.close()
