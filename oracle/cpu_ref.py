@@ -302,3 +302,39 @@ def recognize(channels, db: DictDB, Fs: int = RATE, topn: int = TOPN):
         hashes |= set(fingerprint(ch, Fs=Fs))
     matches, dedup = return_matches(hashes, db)
     return align_matches(matches, dedup, len(hashes), db, topn)
+
+
+def return_matches_apriori(hashes, db: DictDB, batch_size: int = 1000):
+    """recognizer_apriori.py:237-310 (the early-exit variant of return_matches): distinct hashes in first-occurrence
+    order are looked up in batches of `batch_size`; after every batch the matches so far are aligned (topn = TOPN,
+    queried_hashes = len(hashes)) and the loop stops as soon as the leader has more than twice the runner-up's
+    `hashes_matched_in_input` (:302-305); if it never does, songs_arr ends as [] (:307).  Like the reference this
+    raises IndexError while fewer than two songs have matched (`songs_arr[1]`, :303) and UnboundLocalError for an empty
+    query (:310).  Returns (results, dedup_hashes, songs_arr, batches_looked_up)."""
+    hashes = list(hashes)
+    mapper = {}
+    for h, off in hashes:
+        h = h.upper() if isinstance(h, str) else int(h)
+        mapper.setdefault(h, []).append(int(off))
+    values = list(mapper.keys())
+    dedup, results, batches = {}, [], 0
+    for index in range(0, len(values), batch_size):
+        batches += 1
+        for h, sid, off in db.select_multiple(values[index:index + batch_size]):
+            dedup[sid] = dedup.get(sid, 0) + 1
+            for q in mapper[h]:
+                results.append((sid, off - q))
+        songs_arr = align_matches(results, dedup, len(hashes), db)
+        if songs_arr[0]["hashes_matched_in_input"] / 2 > songs_arr[1]["hashes_matched_in_input"]:
+            break
+        songs_arr = []
+    return results, dedup, songs_arr, batches
+
+
+def recognize_apriori(hashes, db: DictDB, batch_size: int = 1000):
+    """recognizer_apriori.py:602-609: the early result if the loop stopped, else align_matches over everything."""
+    hashes = list(hashes)
+    results, dedup, songs_arr, batches = return_matches_apriori(hashes, db, batch_size)
+    if len(songs_arr) > 0:
+        return songs_arr, batches, True
+    return align_matches(results, dedup, len(hashes), db), batches, False
