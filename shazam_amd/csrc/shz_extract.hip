@@ -710,7 +710,12 @@ static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd
   a.window = ctx->d_window;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
-  uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * 3;
+  static const int wgs_per_cu = [] {  // tuning knob: resident stft workgroups per CU (LDS allows 3)
+    const char* e = getenv("SHZ_STFT_WGS_PER_CU");
+    const int v = e ? atoi(e) : 3;
+    return v >= 1 && v <= 3 ? v : 3;
+  }();
+  uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * wgs_per_cu;
   if (grid > frames) grid = frames;
   grid = (grid + 7) & ~7u;  // multiple of 8: see the XCD-aware frame map in the kernel
   hipLaunchKernelGGL(stft_psd_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
