@@ -90,7 +90,7 @@ int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_cl
 int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s);
 
 /* The device radix sort the table build and the vote use (tests / tools): stable sort of n 64-bit keys on bits
- * [bit_lo, bit_hi) -- rounded up to whole digits of 8 or 9 bits --, carrying a payload of val_bytes = 0, 4 or 8
+ * [bit_lo, bit_hi) (other bits are not compared), carrying a payload of val_bytes = 0, 4 or 8
  * bytes per key.  keys / vals are HOST arrays, sorted in place.  n < 2^32. */
 int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_bytes, uint64_t n, uint32_t bit_lo,
                        uint32_t bit_hi);

@@ -197,7 +197,7 @@ class Context:
         return float(g.value)
 
     def sort_pairs(self, keys: np.ndarray, vals=None, bit_lo: int = 0, bit_hi: int = 64):
-        """Stable device radix sort of uint64 keys on bits [bit_lo, bit_hi) (whole 8/9-bit digits), with an optional
+        """Stable device radix sort of uint64 keys on bits [bit_lo, bit_hi), with an optional
         uint32 / uint64 payload; returns sorted copies."""
         k = np.ascontiguousarray(keys, np.uint64).copy()
         v, vb = None, 0

@@ -156,6 +156,7 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 
 template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                                  uint32_t dmask /*digit mask: the last digit may be narrower*/,
                                                                   uint32_t* __restrict__ hist /*[2^BITS][nblocks]*/,
                                                                   uint32_t nblocks) {
   constexpr uint32_t DIG = 1u << BITS;
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) x[r] = k2[r * SORT_THREADS + threadIdx.x];
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) {
-      atomicAdd(&h[(x[r].x >> shift) & (DIG - 1)], 1u);
-      atomicAdd(&h[(x[r].y >> shift) & (DIG - 1)], 1u);
+      atomicAdd(&h[(x[r].x >> shift) & dmask], 1u);
+      atomicAdd(&h[(x[r].y >> shift) & dmask], 1u);
     }
   } else {
     for (int r = 0; r < SORT_ROUNDS; ++r) {
       uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
-      if (i < n) atomicAdd(&h[(keys[i] >> shift) & (DIG - 1)], 1u);
+      if (i < n) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
     }
   }
   __syncthreads();
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                      const void* __restrict__ vals_,
                                                                      uint64_t* __restrict__ okeys,
                                                                      void* __restrict__ ovals_, uint64_t n, int shift,
+                                                                     uint32_t dmask,
                                                                      const uint32_t* __restrict__ offs /*[2^BITS][nblocks]*/,
                                                                      uint32_t nblocks) {
   typedef typename val_t<VB>::type V;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
-    const uint32_t d = (uint32_t)(k[r] >> shift) & (DIG - 1);
+    const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
     unsigned long long peers = __ballot(valid);   // valid lanes of this row holding the same digit
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     if (li < tile_n) {
-      const uint32_t d = (uint32_t)(k[r] >> shift) & (DIG - 1);
+      const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
       const uint32_t pos = wrun[wave][d] + rank[r];
       skey[pos] = k[r];
       if (VB != 0) sval[pos] = pv[r];
@@ -291,27 +293,102 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
     const uint64_t kk = skey[i];
-    const uint32_t d = (uint32_t)(kk >> shift) & (DIG - 1);
+    const uint32_t d = (uint32_t)(kk >> shift) & dmask;
     const uint32_t g = gbase[d] + (i - lstart[d]);
     okeys[g] = kk;
     if (VB != 0) ovals[g] = sval[i];
   }
 }
 
+// Up to one tile of keys: the whole sort in ONE workgroup, all passes inside LDS (ping-pong), 8 bits per pass.  A
+// single query sorts ~2,000 hash elements on ~52 bits: that was 6 passes x 5 launches; the launches, not the work,
+// were a quarter of the match latency of one query.  Same ranking scheme as sort_scatter_kernel.
+template <int VB>
+__global__ __launch_bounds__(SORT_THREADS) void sort_small_kernel(uint64_t* __restrict__ keys, void* __restrict__ vals_,
+                                                                   uint32_t n, int bit_lo, int bit_hi) {
+  typedef typename val_t<VB>::type V;
+  V* vals = (V*)vals_;
+  const int npass = (bit_hi - bit_lo + 7) / 8;
+  __shared__ uint64_t sk[2][SORT_TILE];
+  __shared__ V sv[2][VB ? SORT_TILE : 1];
+  __shared__ uint16_t wrun[4][256];
+  __shared__ uint32_t scan_tmp[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int ROWS = SORT_TILE / SORT_THREADS;
+  for (uint32_t i = threadIdx.x; i < n; i += SORT_THREADS) {
+    sk[0][i] = keys[i];
+    if (VB != 0) sv[0][i] = vals[i];
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int p = 0; p < npass; ++p) {
+    const int cur = p & 1, shift = bit_lo + 8 * p;
+    const uint32_t dmask = (1u << min(8, bit_hi - shift)) - 1u;   // the last digit may be narrower
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wrun[w][threadIdx.x] = 0;
+    __syncthreads();   // also: the previous pass (or the load) has filled sk[cur]
+    uint64_t k[ROWS];
+    uint32_t rank[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+      const bool valid = li < n;
+      k[r] = valid ? sk[cur][li] : 0;
+      const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+      }
+      const uint32_t rk = (uint32_t)__popcll(peers & lt);
+      const uint32_t run = wrun[wave][d];
+      rank[r] = run + rk;
+      if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    {
+      const uint32_t c0 = wrun[0][threadIdx.x], c1 = wrun[1][threadIdx.x], c2 = wrun[2][threadIdx.x], c3 = wrun[3][threadIdx.x];
+      uint32_t tot;
+      const uint32_t ls = block_excl_scan<uint32_t>(c0 + c1 + c2 + c3, &tot, scan_tmp);
+      wrun[0][threadIdx.x] = (uint16_t)ls;
+      wrun[1][threadIdx.x] = (uint16_t)(ls + c0);
+      wrun[2][threadIdx.x] = (uint16_t)(ls + c0 + c1);
+      wrun[3][threadIdx.x] = (uint16_t)(ls + c0 + c1 + c2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+      if (li < n) {
+        const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
+        const uint32_t pos = wrun[wave][d] + rank[r];
+        sk[cur ^ 1][pos] = k[r];
+        if (VB != 0) sv[cur ^ 1][pos] = sv[cur][li];
+      }
+    }
+    __syncthreads();
+  }
+  const int fin = npass & 1;
+  for (uint32_t i = threadIdx.x; i < n; i += SORT_THREADS) {
+    keys[i] = sk[fin][i];
+    if (VB != 0) vals[i] = sv[fin][i];
+  }
+}
+
 template <int BITS>
 static int32_t sort_pass(shz_ctx* ctx, uint32_t nblocks, const uint64_t* kin, const void* vin, uint64_t* kout, void* vout,
-                      int vbytes, uint64_t n, int shift, uint32_t* hist) {
-  hipLaunchKernelGGL(sort_hist_kernel<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, n, shift, hist, nblocks);
+                      int vbytes, uint64_t n, int shift, uint32_t dmask, uint32_t* hist) {
+  hipLaunchKernelGGL(sort_hist_kernel<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, n, shift, dmask, hist, nblocks);
   SHZ_TRY(shz_scan_u32(ctx, hist, hist, (uint64_t)nblocks << BITS, nullptr));
   if (vbytes == 4)
     hipLaunchKernelGGL((sort_scatter_kernel<4, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                       n, shift, (const uint32_t*)hist, nblocks);
+                       n, shift, dmask, (const uint32_t*)hist, nblocks);
   else if (vbytes == 8)
     hipLaunchKernelGGL((sort_scatter_kernel<8, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                       n, shift, (const uint32_t*)hist, nblocks);
+                       n, shift, dmask, (const uint32_t*)hist, nblocks);
   else
     hipLaunchKernelGGL((sort_scatter_kernel<0, BITS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                       n, shift, (const uint32_t*)hist, nblocks);
+                       n, shift, dmask, (const uint32_t*)hist, nblocks);
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
@@ -322,6 +399,16 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
   if (n <= 1 || bit_hi <= bit_lo) return SHZ_OK;
   if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: n must be < 2^32 (got %llu)", (unsigned long long)n);
   if (vbytes != 0 && vbytes != 4 && vbytes != 8) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: payload must be 0, 4 or 8 bytes");
+  if (n <= SORT_TILE) {  // one workgroup, every pass in LDS, sorted in place (*out_sel stays 0)
+    if (vbytes == 4)
+      hipLaunchKernelGGL(sort_small_kernel<4>, dim3(1), dim3(SORT_THREADS), 0, ctx->stream, k0, v0, (uint32_t)n, bit_lo, bit_hi);
+    else if (vbytes == 8)
+      hipLaunchKernelGGL(sort_small_kernel<8>, dim3(1), dim3(SORT_THREADS), 0, ctx->stream, k0, v0, (uint32_t)n, bit_lo, bit_hi);
+    else
+      hipLaunchKernelGGL(sort_small_kernel<0>, dim3(1), dim3(SORT_THREADS), 0, ctx->stream, k0, v0, (uint32_t)n, bit_lo, bit_hi);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
+  }
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
   const int bits = bit_hi - bit_lo;
   const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
@@ -335,10 +422,11 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
   int sel = 0, left = wide ? np9 : np8;
   for (int shift = bit_lo; shift < bit_hi; --left) {
     const int w = wide ? (bit_hi - shift + left - 1) / left : 8;   // wide: spread the bits evenly, each digit <= 9
+    const uint32_t dmask = (1u << std::min(w == 9 ? 9 : 8, bit_hi - shift)) - 1u;   // exactly the bits [bit_lo, bit_hi)
     if (w == 9)
-      SHZ_TRY(sort_pass<9>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, (uint32_t*)hist));
+      SHZ_TRY(sort_pass<9>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, dmask, (uint32_t*)hist));
     else
-      SHZ_TRY(sort_pass<8>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, (uint32_t*)hist));
+      SHZ_TRY(sort_pass<8>(ctx, nblocks, kin, vin, kout, vout, vbytes, n, shift, dmask, (uint32_t*)hist));
     shift += w == 9 ? 9 : 8;
     uint64_t* tk = kin; kin = kout; kout = tk;
     void* tv = vin; vin = vout; vout = tv;

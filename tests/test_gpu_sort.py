@@ -8,12 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _digits(bit_lo, bit_hi):
-    """bits the device actually sorts on: whole digits, 9 wide only where that saves a pass (see shz_sort_u64)"""
-    bits = bit_hi - bit_lo
-    np8, np9 = (bits + 7) // 8, (bits + 8) // 9
-    if np9 >= np8:
-        return bit_lo, min(64, bit_lo + 8 * np8)
-    return bit_lo, bit_hi   # 9,9,..,8 plans cover the range exactly
+    """the sort compares exactly the bits [bit_lo, bit_hi): the last digit of a plan is masked to what is left"""
+    return bit_lo, bit_hi
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 3 * 4096 + 17, 300001])
