@@ -792,17 +792,27 @@ __global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint3
   const bool own = i < m && (nshards <= 1 || shard_of(key32[query_off[0] + i], nshards) == shard);
   const unsigned long long ob = __ballot(own);
   if ((threadIdx.x & 63) == 0 && ob) atomicAdd(err + 2, (uint32_t)__popcll(ob));
+  // largest query offset (the vote key biases deltas by it) and the "offset too wide" flag: one atomic per wave
+  uint32_t o = 0;
+  uint64_t h = 0;
+  if (own) {
+    h = query_off[0] + i;
+    o = q_off[h];
+  }
+  uint32_t omax = o;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, d, 64));
+  if ((threadIdx.x & 63) == 0 && omax) {
+    atomicMax(err + 1, omax);
+    if (omax >> QOFF_BITS) atomicOr(err, 1u);
+  }
   if (i >= m) return;
   if (!own) { c[i] = (uint64_t)nq << QIDX_SHIFT; return; }
-  const uint64_t h = query_off[0] + i;
   uint32_t lo = 0, hi = nq;
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
     if (query_off[mid] <= h) lo = mid; else hi = mid;
   }
-  const uint32_t o = q_off[h];
-  if (o >> QOFF_BITS) atomicOr(err, 1u);
-  atomicMax(err + 1, o);  // largest query offset: the vote key biases deltas by it
   c[i] = ((uint64_t)lo << QIDX_SHIFT) | ((uint64_t)key32[h] << QKEY_SHIFT) | (o & ((1u << QOFF_BITS) - 1));
 }
 
