@@ -1019,6 +1019,8 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
 // first-offset flag = rows matched).  Records are written densely in group order: m_gcount_kernel counts the heads
 // per wave, a scan of those counts gives every wave its first slot.
 #define RG_PER 8
+#define RG_LONG_ITERS 16   // loads of RG_PER votes a thread follows a group before handing it over
+#define RG_LONG_CAP 16384  // long groups per vote pass that get a workgroup of their own
 
 __device__ __forceinline__ int rg_load(const uint64_t* __restrict__ v, uint64_t i0, uint64_t P, uint64_t (&e)[RG_PER]) {
   if (i0 + RG_PER <= P) {
@@ -1077,7 +1079,8 @@ __device__ __forceinline__ void rg_add(rg_state& s, uint64_t val, uint64_t dmask
 __global__ __launch_bounds__(256) void m_reduce_kernel(const uint64_t* __restrict__ v, uint64_t P, m_bits mb,
                                                        const uint32_t* __restrict__ wbase, uint64_t* __restrict__ g_pack,
                                                        uint32_t* __restrict__ g_delta, uint32_t* __restrict__ g_dedup,
-                                                       uint32_t* __restrict__ qstart) {
+                                                       uint32_t* __restrict__ qstart, uint32_t* __restrict__ long_cnt,
+                                                       uint2* __restrict__ long_list) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t i0 = t * RG_PER;
   const int gshift = mb.dbits + 1, qshift = mb.sb + mb.dbits + 1;
@@ -1130,9 +1133,19 @@ __global__ __launch_bounds__(256) void m_reduce_kernel(const uint64_t* __restric
       prev = e[j];
     }
   }
-  // the last group may run on past this thread's votes
+  // the last group may run on past this thread's votes.  A group still open after RG_LONG_ITERS more loads (a clean
+  // query puts thousands of votes on its own song) goes to m_reduce_long_kernel, a workgroup per group, instead of
+  // being walked by this one thread; the list is bounded, a group that does not get a place is walked here after all.
   bool open = n == RG_PER;
+  int iters = 0;
   for (uint64_t i = i0 + RG_PER; open && i < P; i += RG_PER) {
+    if (++iters == RG_LONG_ITERS + 1) {
+      const uint32_t idx = atomicAdd(long_cnt, 1u);
+      if (idx < RG_LONG_CAP) {
+        long_list[idx] = make_uint2(slot, (uint32_t)(i0 + (31 - __clz((int)hm))));   // record slot, first vote of the group
+        return;
+      }
+    }
     uint64_t x[RG_PER];
     const int m = rg_load(v, i, P, x);
 #pragma unroll
@@ -1144,6 +1157,103 @@ __global__ __launch_bounds__(256) void m_reduce_kernel(const uint64_t* __restric
     if (m < RG_PER) open = false;
   }
   emit();
+}
+
+// One workgroup per long group handed over by m_reduce_kernel: wave 0 finds the group's end (64-ary search, the votes
+// are sorted), every thread folds a contiguous piece into (first run, last run, best run between them), thread 0 joins
+// the pieces in order -- runs of one delta that cross piece borders are added up, ties keep the smaller delta.
+struct rg_part {
+  uint64_t hd, td;   // delta of the first / last run of the piece
+  uint32_t hl, tl;   // their lengths (hl == 0: empty piece)
+  uint32_t best, bestd, dedup, single;   // best run strictly between them; flag votes; single: the piece is one run
+};
+
+__global__ __launch_bounds__(256) void m_reduce_long_kernel(const uint64_t* __restrict__ v, uint64_t P, m_bits mb,
+                                                            const uint32_t* __restrict__ long_cnt,
+                                                            const uint2* __restrict__ long_list,
+                                                            uint64_t* __restrict__ g_pack, uint32_t* __restrict__ g_delta,
+                                                            uint32_t* __restrict__ g_dedup) {
+  __shared__ rg_part parts[256];
+  __shared__ uint64_t s_end;
+  const int gshift = mb.dbits + 1;
+  const uint64_t dmask = (1ull << mb.dbits) - 1, smask = (1ull << mb.sb) - 1;
+  const uint32_t nl = min(*long_cnt, (uint32_t)RG_LONG_CAP);
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t L = blockIdx.x; L < nl; L += gridDim.x) {
+    const uint32_t slot = long_list[L].x;
+    const uint64_t h0 = long_list[L].y;
+    const uint64_t grp = v[h0] >> gshift;
+    if (threadIdx.x < 64) {  // last index of the group in [h0, P)
+      uint64_t lo = h0, n = P - h0;
+      while (n > 1) {
+        const uint64_t step = (n + 63) / 64;
+        const uint64_t idx = lo + lane * step;
+        const bool ok = lane * step < n && (v[idx] >> gshift) == grp;   // a prefix of the lanes (lane 0 always)
+        const unsigned long long b = __ballot(ok);
+        const uint32_t last = 63u - (uint32_t)__clzll(b);
+        n = min(step, n - last * step);
+        lo += last * step;
+      }
+      if (lane == 0) s_end = lo + 1;
+    }
+    __syncthreads();
+    const uint64_t end = s_end;
+    const uint64_t per = (end - h0 + 255) / 256;
+    const uint64_t a = min(h0 + threadIdx.x * per, end), b = min(a + per, end);
+    rg_part p;
+    p.hd = p.td = 0;
+    p.hl = p.tl = p.best = p.bestd = p.dedup = 0;
+    p.single = 1;
+    uint64_t curd = ~0ull;
+    uint32_t cur = 0, nruns = 0;
+    for (uint64_t i = a; i < b; ++i) {
+      const uint64_t val = v[i];
+      const uint64_t d = (val >> 1) & dmask;
+      if (d != curd) {
+        if (cur) {  // a run ended inside the piece
+          if (nruns == 0) { p.hd = curd; p.hl = cur; }
+          else if (cur > p.best) { p.best = cur; p.bestd = (uint32_t)curd; }
+          ++nruns;
+        }
+        curd = d;
+        cur = 0;
+      }
+      ++cur;
+      p.dedup += (uint32_t)(val & 1);
+    }
+    if (cur) {
+      if (nruns == 0) { p.hd = curd; p.hl = cur; }          // the piece is one run
+      else { p.td = curd; p.tl = cur; p.single = 0; }      // last run of several
+    }
+    parts[threadIdx.x] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t best = 0, bestd = 0, run = 0, dedup = 0;
+      uint64_t rd = ~0ull;
+      for (int k = 0; k < 256; ++k) {
+        const rg_part& q = parts[k];
+        if (q.hl == 0) continue;
+        dedup += q.dedup;
+        if (q.hd == rd) run += q.hl;
+        else {
+          if (run > best) { best = run; bestd = (uint32_t)rd; }
+          rd = q.hd;
+          run = q.hl;
+        }
+        if (!q.single) {
+          if (run > best) { best = run; bestd = (uint32_t)rd; }
+          if (q.best > best) { best = q.best; bestd = q.bestd; }
+          rd = q.td;
+          run = q.tl;
+        }
+      }
+      if (run > best) { best = run; bestd = (uint32_t)rd; }
+      g_pack[slot] = ((uint64_t)best << 32) | (0xFFFFFFFFu - (uint32_t)(grp & smask));
+      g_delta[slot] = bestd;
+      g_dedup[slot] = dedup;
+    }
+    __syncthreads();
+  }
 }
 
 // group records [r0, r1) of query q: qstart[] holds the first record of every query that has any (0xFFFFFFFF = none)
@@ -1318,21 +1428,26 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
   // group heads per wave -> first record slot of every wave -> one record per (query, sid) group
   const uint32_t nb = nblk((P + RG_PER - 1) / RG_PER), nw = nb * 4;
   void *wc, *gh, *gd, *gdd;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, ((uint64_t)nw * 2 + nq) * 4, &wc));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, ((uint64_t)nw * 2 + nq + 2) * 4 + (uint64_t)RG_LONG_CAP * 8, &wc));
   uint32_t *wcnt = (uint32_t*)wc, *wbase = wcnt + nw, *qstart = wbase + nw;
+  uint32_t* long_cnt = qstart + nq;
+  uint2* long_list = (uint2*)(long_cnt + 1 + ((nw * 2 + nq + 1) & 1));   // 8-byte aligned behind the counter
   hipLaunchKernelGGL(m_gcount_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb.dbits + 1, wcnt);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));
   uint64_t G64 = 0;
   SHZ_HIP(ctx, hipMemcpyAsync(&G64, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(qstart, 0xFF, (uint64_t)nq * 4, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(long_cnt, 0, 4, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t G = (uint32_t)G64;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)G * 8, &gh));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)G * 4, &gd));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)G * 4, &gdd));
   hipLaunchKernelGGL(m_reduce_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb, (const uint32_t*)wbase, (uint64_t*)gh,
-                     (uint32_t*)gd, (uint32_t*)gdd, qstart);
+                     (uint32_t*)gd, (uint32_t*)gdd, qstart, long_cnt, long_list);
+  hipLaunchKernelGGL(m_reduce_long_kernel, dim3(std::min<uint32_t>(1024, nb)), dim3(256), 0, ctx->stream, vs, P, mb,
+                     (const uint32_t*)long_cnt, (const uint2*)long_list, (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
   // groups per query decide the shape: one workgroup per query, or C slices per query and a final ranking
   const uint32_t C = (uint32_t)std::min<uint64_t>(512, ((uint64_t)G / nq + 16383) / 16384);
   if (C <= 1) {

@@ -51,3 +51,32 @@ def test_many_groups_per_query_equal_oracle_vote():
         assert [int(res["dedup"][q, i]) for i in range(len(got))] == [dd[w[0]] for w in want]
         assert int(res["npairs"][q]) == len(m) and int(res["nhash"][q]) == len(hs)
     t.close()
+
+
+def test_long_groups_take_the_workgroup_fold():
+    """(query, song) groups of thousands of votes leave m_reduce_kernel for m_reduce_long_kernel (one workgroup per
+    group): one run of a single delta crossing every piece, and ~10,000 runs with the best count tied from delta 0
+    upwards (the smallest delta must win)."""
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    K = lambda i: np.uint32(((i % 2049) << 20) | (((i // 2049) % 2049) << 8) | 7)  # noqa: E731
+    n_line = 6000
+    keys_a = np.array([K(i) for i in range(n_line)], np.uint32)                 # song 1: distinct hashes, offset = i + 7
+    key_hot = np.uint32((2000 << 20) | (11 << 8) | 1)
+    tk = np.concatenate([keys_a, np.full(10000, key_hot)])
+    ts = np.concatenate([np.full(n_line, 1), np.full(10000, 2)]).astype(np.uint32)
+    to = np.concatenate([np.arange(n_line) + 7, np.arange(10000)]).astype(np.uint32)
+    t = S.Table(ctx)
+    t.insert(tk, ts, to)
+    t.finalize()
+    # query 0: every hash of song 1 at offset i -> 6,000 votes, all delta 7; query 1: the hot hash at offsets 0 and 5
+    qk = np.concatenate([keys_a, np.array([key_hot, key_hot], np.uint32)])
+    qo = np.concatenate([np.arange(n_line), np.array([0, 5])]).astype(np.uint32)
+    qoff = np.array([0, n_line, n_line + 2], np.uint64)
+    res = t.match(qk, qo, qoff, 3)
+    assert int(res["nres"][0]) == 1 and (int(res["sid"][0, 0]), int(res["delta"][0, 0]), int(res["aligned"][0, 0]),
+                                         int(res["dedup"][0, 0])) == (1, 7, n_line, n_line)
+    assert int(res["npairs"][1]) == 20000 and int(res["nres"][1]) == 1
+    # deltas r and r - 5 for r = 0..9999: count 2 for delta 0..9994, count 1 below and above -> (count 2, delta 0)
+    assert (int(res["sid"][1, 0]), int(res["delta"][1, 0]), int(res["aligned"][1, 0]), int(res["dedup"][1, 0])) == (2, 0, 2, 10000)
+    t.close()
