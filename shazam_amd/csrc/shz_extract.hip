@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
 // ======================================================================================
 // K2: peak_pick.  Workgroup = (clip segment, slab of PK_SW bins); streams frames in time.
 // peak <=> A == max over the 21x21 window clipped to the array, and A > amp_min (ties all count).
-// Frequency direction: the row goes through LDS, pair maxima p2[i] = max(x[i], x[i+1]) halve the
-// reads (10 x p2 + 1 x raw).  Time direction: van Herk / Gil-Werman with blocks of 21 frames held
+// Frequency direction: the row goes through LDS as pair maxima p2[i] = max(x[i], x[i+1]) only (one store per
+// value; LDS stores cost three times what reads cost per byte): a 21-column window = 10 disjoint pairs + the pair
+// (c+19, c+20).  Time direction: van Herk / Gil-Werman with blocks of 21 frames held
 // in registers -- prefix max R of the current block, suffix maxima prevS of the previous one, so
 // the 21-frame window max costs 3 max ops per frame instead of 20.
 // POWER = true: values are power (see stft_psd_kernel) and the threshold is applied to
@@ -269,9 +270,10 @@ __device__ __forceinline__ double pk_lds_ld(uint32_t a) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x) : "v"(a), "n"(OFF) : "memory");
   return x;
 }
-// row ROW of the group: x[0..9] = pr2[ROW][c + 2d], x[10] = raw[ROW][c + 20], c = output column (rows are 256 doubles apart)
+// row ROW of the group: x[0..9] = pr2[ROW][c + 2d], x[10] = pr2[ROW][c + 19] (columns c+19, c+20: the overlap with x[9]
+// is harmless for a maximum, and no row of single values has to be stored), c = output column (rows are 256 doubles apart)
 template <int ROW>
-__device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, uint32_t a_raw, double (&x)[11]) {
+__device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, double (&x)[11]) {
   x[0] = pk_lds_ld<ROW * 2048 + 0>(a_pr2);
   x[1] = pk_lds_ld<ROW * 2048 + 16>(a_pr2);
   x[2] = pk_lds_ld<ROW * 2048 + 32>(a_pr2);
@@ -282,7 +284,7 @@ __device__ __forceinline__ void pk_row_reads(uint32_t a_pr2, uint32_t a_raw, dou
   x[7] = pk_lds_ld<ROW * 2048 + 112>(a_pr2);
   x[8] = pk_lds_ld<ROW * 2048 + 128>(a_pr2);
   x[9] = pk_lds_ld<ROW * 2048 + 144>(a_pr2);
-  x[10] = pk_lds_ld<ROW * 2048>(a_raw);
+  x[10] = pk_lds_ld<ROW * 2048 + 152>(a_pr2);
 }
 // wait until at most N of this wave's LDS operations are outstanding; the operands tie the values to the wait so
 // that no use of them is scheduled above it
@@ -310,8 +312,7 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
                                                         uint32_t n_bins, const peak_seg* __restrict__ segs,
                                                         uint32_t n_slabs, double amp_min, double p_lo, double p_hi,
                                                         uint64_t* __restrict__ mask) {
-  __shared__ double raw[PK_PF][256];   // PK_PF consecutive frames' rows of this slab
-  __shared__ double pr2[PK_PF][256];   // pair maxima of the same rows
+  __shared__ double pr2[PK_PF][256];   // pair maxima max(x[c], x[c+1]) of PK_PF consecutive frames' rows of this slab
   const peak_seg sg = segs[blockIdx.y];
   const uint32_t slab = blockIdx.x;
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   // thread -> column of the LDS row: wave w, lane l holds column li = 63 w + l, so lane 63 repeats lane 0 of the next
   // wave.  With that one column of overlap every lane below 63 finds its right neighbour in its own wave: the pair
   // maxima come from a DPP wave shift instead of a second trip through LDS (one barrier and seven LDS reads less
-  // per group).  Lane 63 loads and stores the raw value like its twin but produces no pair maximum and no output.
+  // per group).  Lane 63 loads the value like its twin but produces no pair maximum and no output.
   const int li = 63 * wave + lane;  // = column - (slab*PK_SW - 10); li >= PK_COLS (wave 3, lanes 59..63) is idle
   const long long col = (long long)slab * PK_SW - 10 + li;
   const bool loads = li < PK_COLS && col >= 0 && col < (long long)n_bins;
@@ -330,7 +331,6 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   const int end = (int)sg.t1 + 10;  // last iteration decides frame t1-1
   const double* src = A + (uint64_t)sg.gframe0 * row_stride + (loads ? col : 0);
   const uint32_t a_pr2 = (uint32_t)(uintptr_t)(pk_lds_cd*)&pr2[0][reads ? li - 10 : 0];   // window = columns li-10 .. li+10
-  const uint32_t a_raw = (uint32_t)(uintptr_t)(pk_lds_cd*)&raw[0][reads ? li + 10 : 0];
 
   double prevS[21], cur[21], pre[PK_PF];
   uint32_t fc = 0, fp = 0, sp = 0;  // row-max flags of the current / previous block, suffix-max flags
@@ -358,13 +358,12 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
       if (li < PK_COLS) {
 #pragma unroll
         for (int i = 0; i < PK_PF; ++i) {
-          raw[i][li] = v[i];
           const double nb = pk_wave_shl1(v[i]);        // column li + 1 (idle lanes hold -inf)
           if (lane < 63) pr2[i][li] = fmax(v[i], nb);
         }
       }
       __syncthreads();
-      // Row maxima over columns j .. j+20 = pairs (j, j+1) .. (j+18, j+19) and column j+20.  The eleven reads of a
+      // Row maxima over columns j .. j+20 = pairs (j, j+1) .. (j+18, j+19) and the pair (j+19, j+20).  The eleven reads of a
       // row are single ds_read_b64 (2 LDS-array cycles each); left to the compiler they are fused in pairs into
       // ds_read2_b64 at 8 cycles per pair (PMC: 2,201 -> 1,403 LDS-array cycles per frame).  Two rows are in
       // flight: the reads of row i+1 are issued before row i is reduced.
@@ -372,13 +371,13 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
       for (int i = 0; i < PK_PF; ++i) m1[i] = NEG;
       if (reads) {
         double xa[11], xb[11];
-        pk_row_reads<0>(a_pr2, a_raw, xa);
-        pk_row_reads<1>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[0] = pk_row_max(xa);
-        pk_row_reads<2>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[1] = pk_row_max(xb);
-        pk_row_reads<3>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[2] = pk_row_max(xa);
-        pk_row_reads<4>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[3] = pk_row_max(xb);
-        pk_row_reads<5>(a_pr2, a_raw, xb); PK_WAIT(xa, 11); m1[4] = pk_row_max(xa);
-        pk_row_reads<6>(a_pr2, a_raw, xa); PK_WAIT(xb, 11); m1[5] = pk_row_max(xb);
+        pk_row_reads<0>(a_pr2, xa);
+        pk_row_reads<1>(a_pr2, xb); PK_WAIT(xa, 11); m1[0] = pk_row_max(xa);
+        pk_row_reads<2>(a_pr2, xa); PK_WAIT(xb, 11); m1[1] = pk_row_max(xb);
+        pk_row_reads<3>(a_pr2, xb); PK_WAIT(xa, 11); m1[2] = pk_row_max(xa);
+        pk_row_reads<4>(a_pr2, xa); PK_WAIT(xb, 11); m1[3] = pk_row_max(xb);
+        pk_row_reads<5>(a_pr2, xb); PK_WAIT(xa, 11); m1[4] = pk_row_max(xa);
+        pk_row_reads<6>(a_pr2, xa); PK_WAIT(xb, 11); m1[5] = pk_row_max(xb);
         PK_WAIT(xa, 0); m1[6] = pk_row_max(xa);
       }
       // time direction (registers only)
