@@ -192,46 +192,51 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       for (int r = 0; r < 8; ++r) buf[(base + 64 * r) ^ ks] = v[r];
       __syncthreads();
     }
-    // pass 4: Ns = 512, radix 4, two butterflies per thread (k = j and k = j + 256);
-    // twiddles W_2048^(k t) = W4096^(2 k t)
+    // pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
+    // W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
+    // Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
+    // thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
+    // b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
     {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
-      __syncthreads();
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = j + 256 * h;
-        const cplx w1 = tw[2 * k];
+      const int bb = j ? 512 - j : 256;
+      const int swb = (bb >> 3) & 7;
+      cplx A0 = buf[j ^ sw], A1 = buf[(j + 512) ^ sw], A2 = buf[(j + 1024) ^ sw], A3 = buf[(j + 1536) ^ sw];
+      cplx B0 = buf[bb ^ swb], B1 = buf[(bb + 512) ^ swb], B2 = buf[(bb + 1024) ^ swb], B3 = buf[(bb + 1536) ^ swb];
+      {
+        const cplx w1 = tw[2 * j];
         const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-        cplx c0 = v[h], c1 = cmul(v[h + 2], w1), c2 = cmul(v[h + 4], w2), c3 = cmul(v[h + 6], w3);
-        dft4(c0, c1, c2, c3);
-        buf[k ^ sw] = c0;
-        buf[(k + 512) ^ sw] = c1;
-        buf[(k + 1024) ^ sw] = c2;
-        buf[(k + 1536) ^ sw] = c3;
+        A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
+        dft4(A0, A1, A2, A3);
       }
-      __syncthreads();
-    }
-    if (g + gstep < gend) issue_loads(g + gstep);  // in flight across the stores below
-    // split post-pass: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O); power, scale
-    double* orow = a.out + (uint64_t)g * DB_STRIDE;
-    const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      const int k = j + 256 * m;
-      if (m == 4 && j != 0) break;
-      const int km = (2048 - k) & 2047;
-      const cplx zk = buf[SWZ(k)];
-      const cplx zm = buf[SWZ(km)];
-      const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
-      const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
-      const cplx wo = cmul(tw[k], o);
-      const cplx xa = cadd(e, wo), xb = csub(e, wo);
-      const double sc = (k != 0) ? scale2 : a.scale;  // bin 2048 pairs with k = 0: both unscaled
-      const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
-      const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
-      orow[k] = (pa != 0.0) ? pa : 1.0;
-      if (k != 1024) orow[2048 - k] = (pb != 0.0) ? pb : 1.0;
+      {
+        const cplx w1 = tw[2 * bb];
+        const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+        B1 = cmul(B1, w1); B2 = cmul(B2, w2); B3 = cmul(B3, w3);
+        dft4(B0, B1, B2, B3);
+      }
+      if (g + gstep < gend) issue_loads(g + gstep);  // in flight across the stores below
+      double* orow = a.out + (uint64_t)g * DB_STRIDE;
+      const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
+      // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024]
+      auto pair_out = [&](int k, cplx zk, cplx zm) {
+        const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
+        const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
+        const cplx wo = cmul(tw[k], o);
+        const cplx xa = cadd(e, wo), xb = csub(e, wo);
+        const double sc = (k != 0) ? scale2 : a.scale;  // bin 2048 pairs with k = 0: both unscaled
+        const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
+        const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
+        orow[k] = (pa != 0.0) ? pa : 1.0;
+        if (k != 1024) orow[2048 - k] = (pb != 0.0) ? pb : 1.0;
+      };
+      // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
+      // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
+      const bool t0 = j == 0;
+      pair_out(t0 ? 256 : 512 - j, B0, t0 ? B3 : A3);   // ordered so that each pair frees its operands early
+      pair_out(j, A0, t0 ? A0 : B3);
+      pair_out(j + 512, A1, t0 ? A3 : B2);
+      pair_out(t0 ? 768 : 1024 - j, B1, t0 ? B2 : A2);
+      if (t0) pair_out(1024, A2, A2);
     }
     __syncthreads();  // buf is rewritten by the next frame's pass 1
   }
