@@ -41,7 +41,7 @@ def pmc_traffic(kernel, frames_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), scaled to this
     run's frames per launch; None when no profile of that kernel is committed."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))
         k = {"stft_psd": "stft_psd_kernel", "peak_pick": "peak_pick_kernel<true>"}[kernel]
         return prof["kernels"][k]["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000)
     except Exception:
@@ -274,7 +274,7 @@ def main():
     bytes_per_frame = {"stft_psd": STFT_BYTES_PER_FRAME, "peak_pick": 2049 * 8 + 288}.get(dom, STFT_BYTES_PER_FRAME)
     achieved = frames_per_launch * bytes_per_frame / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch), "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01e_pmc_traffic.json)",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch), "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01g_pmc_traffic.json)",
                 "accounting": f"kernel I/O bytes: {bytes_per_frame} B/frame x {frames_per_launch:.0f} frames/launch / "
                               f"{avg_ms:.3f} ms avg launch (HIP events, {dom_launches} launches in the timed region)",
                 "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kms.items()},
