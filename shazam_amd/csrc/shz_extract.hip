@@ -471,25 +471,32 @@ __global__ __launch_bounds__(256) void peak_zero_plateau_kernel(uint64_t* __rest
 }
 
 // K3: expand peak masks into the ordered peak list.  One thread per mask word.
-__global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __restrict__ mask,
-                                                          const uint32_t* __restrict__ word_off, uint64_t n_words,
-                                                          uint32_t n_slabs, const uint32_t* __restrict__ clip_foff,
-                                                          uint32_t n_clips, uint16_t* __restrict__ peak_f,
-                                                          uint32_t* __restrict__ peak_t) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  uint64_t m = mask[w];
-  if (!m) return;
-  const uint32_t per_frame = n_slabs * 4;
-  const uint32_t g = (uint32_t)(w / per_frame);
-  const uint32_t rem = (uint32_t)(w % per_frame);
-  const uint32_t slab = rem >> 2, wv = rem & 3;
+// frame_t[g] = index of frame g inside its clip (one binary search per frame instead of one per mask word)
+__global__ void frame_time_kernel(const uint32_t* __restrict__ clip_foff, uint32_t n_clips, uint32_t frames,
+                                  uint32_t* __restrict__ frame_t) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= frames) return;
   uint32_t lo = 0, hi = n_clips;
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
     if (clip_foff[mid] <= g) lo = mid; else hi = mid;
   }
-  const uint32_t t = g - clip_foff[lo];
+  frame_t[g] = g - clip_foff[lo];
+}
+
+__global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __restrict__ mask,
+                                                          const uint32_t* __restrict__ word_off, uint32_t n_words,
+                                                          uint32_t n_slabs, const uint32_t* __restrict__ frame_t,
+                                                          uint16_t* __restrict__ peak_f, uint32_t* __restrict__ peak_t) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t m = mask[w];
+  if (!m) return;
+  const uint32_t per_frame = n_slabs * 4;
+  const uint32_t g = w / per_frame;
+  const uint32_t rem = w - g * per_frame;
+  const uint32_t slab = rem >> 2, wv = rem & 3;
+  const uint32_t t = frame_t[g];
   uint32_t o = word_off[w];
   while (m) {
     const int b = __ffsll((long long)m) - 1;
@@ -764,8 +771,13 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, tot * 4 + 64, &pt));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(nc + 1) * 4 + 64, &pc));
     if (n_words) {
+      if (n_words >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "too many mask words in one sub-batch");
+      void* ft;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)frames * 4 + 64, &ft));
+      hipLaunchKernelGGL(frame_time_kernel, dim3((frames + 255) / 256), dim3(256), 0, ctx->stream, sd.d_foff, nc, frames,
+                         (uint32_t*)ft);
       hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
-                         (const uint64_t*)d_mask, (const uint32_t*)d_woff, n_words, n_slabs, sd.d_foff, nc,
+                         (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, n_slabs, (const uint32_t*)ft,
                          (uint16_t*)pf, (uint32_t*)pt);
       SHZ_HIP(ctx, hipGetLastError());
     }
