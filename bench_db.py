@@ -142,6 +142,7 @@ def main():
     t_match = float((lat * np.minimum(a.match_batch, nq - np.arange(0, nq, a.match_batch))).sum() / 1e3)
     out = {"metric": "query_match_ms_per_query_batched", "value": float(np.median(lat)), "unit": "ms/query",
            "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "qps": nq / t_match,
+           "ms_per_query_by_batch": [round(float(x), 5) for x in lat[:64]],
            "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
            "config": {"workload": f"{a.songs} x {a.seconds:.0f} s tonal+noise tracks in one HBM table; {nq} x "
                                   f"{a.query_seconds:.0f} s queries at arbitrary offsets, SNR {a.snr} dB, batches of {a.match_batch}",

@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01f; mkdir -p $O
+O=gpurun_out/r01g; mkdir -p $O
 B="timeout -k 10 600 python bench_db.py"
 $B --songs 20000 --queries 4000 --snr 10 --shards 1 > $O/bench_db_20k_shards1.json
 $B --songs 20000 --queries 4000 --snr 10 --shards 8 > $O/bench_db_20k_shards8.json

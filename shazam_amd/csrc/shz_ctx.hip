@@ -9,13 +9,16 @@ int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out) {
   shz_buf& b = ctx->ws[slot];
   if (bytes == 0) bytes = 256;
   if (b.cap < bytes) {
+    const bool regrow = b.p != nullptr;
     if (b.p) {
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
       SHZ_HIP(ctx, hipFree(b.p));
       b.p = nullptr;
       b.cap = 0;
     }
-    uint64_t want = (bytes + (bytes >> 3) + 4095) & ~uint64_t(4095);  // 12.5 % slack against regrowth
+    // slack against regrowth: 12.5 %, 25 % for a slot that has grown before (its size varies from call to call; a
+    // hipFree + hipMalloc pair costs milliseconds to tens of milliseconds and showed as slow match batches in a stream)
+    uint64_t want = (bytes + (bytes >> (regrow ? 2 : 3)) + 4095) & ~uint64_t(4095);
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
       want = (bytes + 4095) & ~uint64_t(4095);
