@@ -141,8 +141,8 @@ int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t
   rccl_api* r = rccl();
   if (scount[c->rank] != rcount[c->rank]) SHZ_FAIL(ctx, SHZ_E_INVALID, "alltoallv: self block sizes differ");
   if (scount[c->rank])
-    SHZ_HIP(ctx, hipMemcpyAsync((char*)d_recv + rdispl[c->rank], (const char*)d_send + sdispl[c->rank], scount[c->rank],
-                                hipMemcpyDeviceToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, (char*)d_recv + rdispl[c->rank], (const char*)d_send + sdispl[c->rank], scount[c->rank],
+                                hipMemcpyDeviceToDevice));
   if (c->nranks == 1) return SHZ_OK;
   if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclSend/ncclRecv");
   SHZ_NCCL(ctx, r->GroupStart());

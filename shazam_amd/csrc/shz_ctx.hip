@@ -1,6 +1,8 @@
 // Context, device memory, timers and the synthetic-PCM generator of libshz.so.
 #include <math.h>
 
+#include <algorithm>
+
 #include "shz_internal.h"
 
 extern "C" const char* shz_version(void) { return "shz 0.1 (gfx950)"; }
@@ -30,6 +32,57 @@ int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out) {
   }
   *out = b.p;
   return SHZ_OK;
+}
+
+#define SHZ_PIN_CHUNK (8ull << 20)
+
+hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return hipSuccess;
+  const bool h2d = kind == hipMemcpyHostToDevice, d2h = kind == hipMemcpyDeviceToHost;
+  if ((!h2d && !d2h) || bytes < (16u << 10) || bytes > (64ull << 20)) return hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  hipError_t e;
+  for (int i = 0; i < 2; ++i)
+    if (!ctx->pin[i]) {
+      if ((e = hipHostMalloc(&ctx->pin[i], SHZ_PIN_CHUNK, hipHostMallocDefault)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+  auto wait_free = [&](int i) -> hipError_t {
+    if (!ctx->pin_busy[i]) return hipSuccess;
+    ctx->pin_busy[i] = false;
+    return hipEventSynchronize(ctx->pin_ev[i]);
+  };
+  const uint64_t nch = (bytes + SHZ_PIN_CHUNK - 1) / SHZ_PIN_CHUNK;
+  if (h2d) {
+    for (uint64_t k = 0; k < nch; ++k) {
+      const int i = (int)(k & 1);
+      const uint64_t off = k * SHZ_PIN_CHUNK, n = std::min<uint64_t>(SHZ_PIN_CHUNK, bytes - off);
+      if ((e = wait_free(i)) != hipSuccess) return e;
+      memcpy(ctx->pin[i], (const char*)src + off, n);
+      if ((e = hipMemcpyAsync((char*)dst + off, ctx->pin[i], n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
+      if ((e = hipEventRecord(ctx->pin_ev[i], ctx->stream)) != hipSuccess) return e;
+      ctx->pin_busy[i] = true;
+    }
+    return hipSuccess;
+  }
+  auto issue = [&](uint64_t k) -> hipError_t {
+    const int i = (int)(k & 1);
+    const uint64_t off = k * SHZ_PIN_CHUNK, n = std::min<uint64_t>(SHZ_PIN_CHUNK, bytes - off);
+    hipError_t r = wait_free(i);
+    if (r != hipSuccess) return r;
+    if ((r = hipMemcpyAsync(ctx->pin[i], (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return r;
+    if ((r = hipEventRecord(ctx->pin_ev[i], ctx->stream)) != hipSuccess) return r;
+    ctx->pin_busy[i] = true;
+    return hipSuccess;
+  };
+  if ((e = issue(0)) != hipSuccess) return e;
+  for (uint64_t k = 0; k < nch; ++k) {
+    if (k + 1 < nch && (e = issue(k + 1)) != hipSuccess) return e;
+    const int i = (int)(k & 1);
+    const uint64_t off = k * SHZ_PIN_CHUNK, n = std::min<uint64_t>(SHZ_PIN_CHUNK, bytes - off);
+    if ((e = wait_free(i)) != hipSuccess) return e;
+    memcpy((char*)dst + off, ctx->pin[i], n);
+  }
+  return hipSuccess;
 }
 
 extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
@@ -88,6 +141,10 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
   if (ctx->d_window) (void)hipFree(ctx->d_window);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+    if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+  }
   if (ctx->tev_init)
     for (auto& e : ctx->tev) {
       (void)hipEventDestroy(e[0]);
@@ -136,7 +193,7 @@ extern "C" int32_t shz_dev_free(shz_ctx* ctx, void* dptr) {
 extern "C" int32_t shz_copy_h2d(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return SHZ_E_INVALID;
   if (!bytes) return SHZ_OK;
-  SHZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, dst, src, bytes, hipMemcpyHostToDevice));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -144,7 +201,7 @@ extern "C" int32_t shz_copy_h2d(shz_ctx* ctx, void* dst, const void* src, uint64
 extern "C" int32_t shz_copy_d2h(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return SHZ_E_INVALID;
   if (!bytes) return SHZ_OK;
-  SHZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, dst, src, bytes, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -365,7 +422,7 @@ extern "C" int32_t shz_sumsq_i16(shz_ctx* ctx, const int16_t* dev_pcm, uint32_t 
   dim3 grid((unsigned)(per > 64 ? 64 : (per ? per : 1)), n_clips);
   hipLaunchKernelGGL(sumsq_i16_kernel, grid, dim3(256), 0, ctx->stream, dev_pcm, n_samples, (unsigned long long*)d);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_HIP(ctx, hipMemcpyAsync(out_host, d, 8ull * n_clips, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_host, d, 8ull * n_clips, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -378,7 +435,7 @@ extern "C" int32_t shz_mix_i16(shz_ctx* ctx, const int16_t* dev_sig, const int16
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void* d;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, 8ull * n_clips, &d));
-  SHZ_HIP(ctx, hipMemcpyAsync(d, scale_host, 8ull * n_clips, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d, scale_host, 8ull * n_clips, hipMemcpyHostToDevice));
   uint64_t per = (n_samples + 255) / 256;
   dim3 grid((unsigned)(per > 64 ? 64 : per), n_clips);
   hipLaunchKernelGGL(mix_i16_kernel, grid, dim3(256), 0, ctx->stream, dev_sig, dev_noise, n_samples, (const double*)d, dev_out);

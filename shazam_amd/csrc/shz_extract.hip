@@ -681,11 +681,10 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
   sd.d_foff = (uint32_t*)(sd.d_len + nc);
   sd.d_segs = (peak_seg*)p1;
   sd.n_segs = (uint32_t)segs.size();
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_soff, soff.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_len, len.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_foff, sd.foff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice,
-                              ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_soff, soff.data(), nc * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_len, len.data(), nc * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_foff, sd.foff.data(), (nc + 1) * 4, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
   return SHZ_OK;
 }
@@ -701,7 +700,7 @@ static int32_t stage_pcm(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_
   }
   void* p;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PCM, (s1 - s0) * 2 + 64, &p));
-  if (s1 > s0) SHZ_HIP(ctx, hipMemcpyAsync(p, pcm + s0, (s1 - s0) * 2, hipMemcpyHostToDevice, ctx->stream));
+  if (s1 > s0) SHZ_HIP(ctx, shz_memcpy(ctx, p, pcm + s0, (s1 - s0) * 2, hipMemcpyHostToDevice));
   *d_pcm = (const int16_t*)p;
   *base_off = s0;
   return SHZ_OK;
@@ -764,7 +763,7 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
   {
     shz_prof_scope ps(ctx, 2);
     SHZ_TRY(shz_scan_popc64(ctx, (const uint64_t*)d_mask, (uint32_t*)d_woff, n_words, (uint64_t*)d_tot));
-    SHZ_HIP(ctx, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, &tot, d_tot, 8, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     void *pf, *pt, *pc;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, tot * 2 + 64, &pf));
@@ -822,8 +821,8 @@ static int32_t run_pairs(shz_ctx* ctx, const uint16_t* d_pf, const uint32_t* d_p
   SHZ_HIP(ctx, hipGetLastError());
   uint64_t tot = 0;
   clip_hoff->resize(nc + 1);
-  SHZ_HIP(ctx, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(clip_hoff->data(), d_choff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, &tot, d_tot, 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, clip_hoff->data(), d_choff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n_hashes = tot;
   return SHZ_OK;
@@ -869,7 +868,7 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
       tr_pos += (uint64_t)F * SHZ_NBINS;
     }
     SHZ_HIP(ctx, hipGetLastError());
-    SHZ_HIP(ctx, hipMemcpyAsync(out_db + out_pos, d_tr, tr_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, out_db + out_pos, d_tr, tr_pos * 8, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out_pos += tr_pos;
   }
@@ -906,14 +905,14 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
                       &d_pcoff, &n_peaks));
     if (!want_hashes) {
       std::vector<uint32_t> pco(nc + 1);
-      SHZ_HIP(ctx, hipMemcpyAsync(pco.data(), d_pcoff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, shz_memcpy(ctx, pco.data(), d_pcoff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost));
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (peak_off)
         for (uint32_t i = 0; i < nc; ++i) peak_off[sb.c0 + i + 1] = total + pco[i + 1];
       if (total + n_peaks <= cap && n_peaks) {
         const hipMemcpyKind kd = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        SHZ_HIP(ctx, hipMemcpyAsync(peak_f + total, d_pf, (uint64_t)n_peaks * 2, kd, ctx->stream));
-        SHZ_HIP(ctx, hipMemcpyAsync(peak_t + total, d_pt, (uint64_t)n_peaks * 4, kd, ctx->stream));
+        SHZ_HIP(ctx, shz_memcpy(ctx, peak_f + total, d_pf, (uint64_t)n_peaks * 2, kd));
+        SHZ_HIP(ctx, shz_memcpy(ctx, peak_t + total, d_pt, (uint64_t)n_peaks * 4, kd));
         SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
       }
       total += n_peaks;
@@ -945,8 +944,8 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     if (hash_off)
       for (uint32_t i = 0; i < nc; ++i) hash_off[sb.c0 + i + 1] = total + choff[i + 1];
     if (!out_dev && total + n_h <= cap && n_h) {
-      SHZ_HIP(ctx, hipMemcpyAsync(key32 + total, d_key, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipMemcpyAsync(t1 + total, d_t1, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, shz_memcpy(ctx, key32 + total, d_key, n_h * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, t1 + total, d_t1, n_h * 4, hipMemcpyDeviceToHost));
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     total += n_h;
@@ -984,7 +983,7 @@ extern "C" int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t
   void *d_in, *d_db;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)n_rows * n_cols * 8, &d_in));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)n_cols * stride * 8, &d_db));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_in, arr2d, (uint64_t)n_rows * n_cols * 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_in, arr2d, (uint64_t)n_rows * n_cols * 8, hipMemcpyHostToDevice));
   dim3 grid((n_cols + 31) / 32, (n_rows + 31) / 32);
   hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(32, 8), 0, ctx->stream, (const double*)d_in, n_rows, n_cols, stride,
                      (double*)d_db);
@@ -1000,8 +999,8 @@ extern "C" int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t
   sd.d_foff = (uint32_t*)p0;
   sd.d_segs = (peak_seg*)p1;
   sd.n_segs = (uint32_t)segs.size();
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_foff, foff, 8, hipMemcpyHostToDevice, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_foff, foff, 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint16_t* d_pf;
   uint32_t *d_pt, *d_pcoff, n_peaks;
@@ -1011,8 +1010,8 @@ extern "C" int32_t shz_peaks_from_db(shz_ctx* ctx, const double* arr2d, uint32_t
   if (!n_peaks) return SHZ_OK;
   std::vector<uint16_t> pf(n_peaks);
   std::vector<uint32_t> pt(n_peaks), idx(n_peaks);
-  SHZ_HIP(ctx, hipMemcpyAsync(pf.data(), d_pf, (uint64_t)n_peaks * 2, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(pt.data(), d_pt, (uint64_t)n_peaks * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, pf.data(), d_pf, (uint64_t)n_peaks * 2, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, pt.data(), d_pt, (uint64_t)n_peaks * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // device order is (t asc, f asc); np.where order is (f asc, t asc): stable re-sort by f
   for (uint32_t i = 0; i < n_peaks; ++i) idx[i] = i;
@@ -1045,10 +1044,10 @@ extern "C" int32_t shz_pair_hash(shz_ctx* ctx, const uint16_t* peak_f, const uin
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, upper * 4 + 64, &pk));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, upper * 4 + 64, &pt1));
   if (n) {
-    SHZ_HIP(ctx, hipMemcpyAsync(pf, peak_f + peak_off[0], n * 2, hipMemcpyHostToDevice, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(pt, peak_t + peak_off[0], n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, pf, peak_f + peak_off[0], n * 2, hipMemcpyHostToDevice));
+    SHZ_HIP(ctx, shz_memcpy(ctx, pt, peak_t + peak_off[0], n * 4, hipMemcpyHostToDevice));
   }
-  SHZ_HIP(ctx, hipMemcpyAsync(pc, pco.data(), (uint64_t)(n_clips + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, pc, pco.data(), (uint64_t)(n_clips + 1) * 4, hipMemcpyHostToDevice));
   uint64_t n_h = 0;
   std::vector<uint32_t> choff;
   SHZ_TRY(run_pairs(ctx, (const uint16_t*)pf, (const uint32_t*)pt, (const uint32_t*)pc, n_clips, (uint32_t)n, fan_value,
@@ -1058,8 +1057,8 @@ extern "C" int32_t shz_pair_hash(shz_ctx* ctx, const uint16_t* peak_f, const uin
   if (count) *count = n_h;
   if (n_h > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu hashes", (unsigned long long)n_h);
   if (n_h) {
-    SHZ_HIP(ctx, hipMemcpyAsync(key32, pk, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(t1, pt1, n_h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, key32, pk, n_h * 4, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, t1, pt1, n_h * 4, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return SHZ_OK;

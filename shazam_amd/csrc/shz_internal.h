@@ -88,7 +88,19 @@ struct shz_ctx {
   std::vector<struct shz_prof_rec> prof_free;
   // match stats
   uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
+  // pinned bounce buffers of shz_memcpy (two halves, an event each)
+  void* pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_busy[2] = {false, false};
 };
+
+// Copy on ctx->stream.  Host <-> device copies of 16 KB .. 64 MB go through pinned bounce buffers owned by the context
+// instead of handing the caller's pages to the driver: HIP registers pageable memory of that size with the kernel
+// driver for the DMA, and when the application later frees it the driver evicts and restores every queue of the
+// process -- 20-28 ms in the next device call (seen as every other query batch of a stream being 6x slower).  Smaller
+// copies use the runtime's own staging, larger ones amortise one such event.  H2D: the source may be reused on return;
+// D2H (bounced sizes): the data is there on return.
+hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, hipMemcpyKind kind);
 
 // ensure ws slot has >= bytes (grow-only; contents not preserved)
 int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out);

@@ -449,13 +449,13 @@ extern "C" int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint
   if (val_bytes) {
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, n * val_bytes, &v0));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, n * val_bytes, &v1));
-    SHZ_HIP(ctx, hipMemcpyAsync(v0, vals, n * val_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, v0, vals, n * val_bytes, hipMemcpyHostToDevice));
   }
-  SHZ_HIP(ctx, hipMemcpyAsync(k0, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 8, hipMemcpyHostToDevice));
   int sel = 0;
   SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)k0, (uint64_t*)k1, v0, v1, (int)val_bytes, n, (int)bit_lo, (int)bit_hi, &sel));
-  SHZ_HIP(ctx, hipMemcpyAsync(keys, sel ? k1 : k0, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (val_bytes) SHZ_HIP(ctx, hipMemcpyAsync(vals, sel ? v1 : v0, n * val_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, keys, sel ? k1 : k0, n * 8, hipMemcpyDeviceToHost));
+  if (val_bytes) SHZ_HIP(ctx, shz_memcpy(ctx, vals, sel ? v1 : v0, n * val_bytes, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }

@@ -72,14 +72,14 @@ extern "C" int32_t shz_sha1_prefix(shz_ctx* ctx, const uint32_t* key32, uint64_t
     void *pk, *po;
     if (!(flags & SHZ_IN_DEVICE)) {
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, m * 4, &pk));
-      SHZ_HIP(ctx, hipMemcpyAsync(pk, key32 + s, m * 4, hipMemcpyHostToDevice, ctx->stream));
+      SHZ_HIP(ctx, shz_memcpy(ctx, pk, key32 + s, m * 4, hipMemcpyHostToDevice));
       d_key = (const uint32_t*)pk;
     }
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, m * 10, &po));
     hipLaunchKernelGGL(sha1_prefix_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_key, m,
                        (uint8_t*)po);
     SHZ_HIP(ctx, hipGetLastError());
-    SHZ_HIP(ctx, hipMemcpyAsync(out10 + s * 10, po, m * 10, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, out10 + s * 10, po, m * 10, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return SHZ_OK;

@@ -105,15 +105,15 @@ extern "C" int32_t shz_sha1_invert(shz_ctx* ctx, const uint8_t* digests10, uint6
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, n * 8, &dh));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n * 2 + 64, &dl));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, n * 4, &dk));
-  SHZ_HIP(ctx, hipMemcpyAsync(dh, shi.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(dl, slo.data(), n * 2, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, dh, shi.data(), n * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, dl, slo.data(), n * 2, hipMemcpyHostToDevice));
   SHZ_HIP(ctx, hipMemsetAsync(dk, 0xFF, n * 4, ctx->stream));
   const uint32_t per_f1 = SHZ_NBINS * (SHZ_MAX_DT + 1);
   hipLaunchKernelGGL(sha1_invert_kernel, dim3((per_f1 + 255) / 256, SHZ_NBINS), dim3(256), 0, ctx->stream,
                      (const uint64_t*)dh, (const uint16_t*)dl, (uint32_t)n, (uint32_t*)dk);
   SHZ_HIP(ctx, hipGetLastError());
   std::vector<uint32_t> sk(n);
-  SHZ_HIP(ctx, hipMemcpyAsync(sk.data(), dk, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, sk.data(), dk, n * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (uint64_t i = 0; i < n; ++i) key32_out[order[i]] = sk[i];
   return SHZ_OK;

@@ -258,7 +258,7 @@ static int32_t stage_reserve(shz_table* t, uint64_t extra) {
   }
   uint32_t** old[3] = {&t->skey, &t->ssid, &t->soff};
   for (int i = 0; i < 3; ++i) {
-    if (t->ns) SHZ_HIP(ctx, hipMemcpyAsync(np[i], *old[i], t->ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (t->ns) SHZ_HIP(ctx, shz_memcpy(ctx, np[i], *old[i], t->ns * 4, hipMemcpyDeviceToDevice));
   }
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 3; ++i) {
@@ -278,9 +278,9 @@ extern "C" int32_t shz_table_insert(shz_table* t, const uint32_t* key32, const u
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   SHZ_TRY(stage_reserve(t, n));
   const hipMemcpyKind kd = (flags & SHZ_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  SHZ_HIP(ctx, hipMemcpyAsync(t->skey + t->ns, key32, n * 4, kd, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(t->ssid + t->ns, sid, n * 4, kd, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(t->soff + t->ns, off, n * 4, kd, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, t->skey + t->ns, key32, n * 4, kd));
+  SHZ_HIP(ctx, shz_memcpy(ctx, t->ssid + t->ns, sid, n * 4, kd));
+  SHZ_HIP(ctx, shz_memcpy(ctx, t->soff + t->ns, off, n * 4, kd));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->ns += n;
   return SHZ_OK;
@@ -299,15 +299,15 @@ extern "C" int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, c
   SHZ_TRY(stage_reserve(t, n));
   void* d_ho;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(n_clips + 1) * 8, &d_ho));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_ho, hash_off, (uint64_t)(n_clips + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_ho, hash_off, (uint64_t)(n_clips + 1) * 8, hipMemcpyHostToDevice));
   const uint32_t *dk = key32, *dt = t1;
   if (!(flags & SHZ_IN_DEVICE)) {
     void *a, *b;
     const uint64_t hi = hash_off[n_clips];
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, hi * 4, &a));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, hi * 4, &b));
-    SHZ_HIP(ctx, hipMemcpyAsync(a, key32, hi * 4, hipMemcpyHostToDevice, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(b, t1, hi * 4, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, a, key32, hi * 4, hipMemcpyHostToDevice));
+    SHZ_HIP(ctx, shz_memcpy(ctx, b, t1, hi * 4, hipMemcpyHostToDevice));
     dk = (const uint32_t*)a;
     dt = (const uint32_t*)b;
   }
@@ -383,7 +383,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
                        ssid, soff, ns, (uint32_t*)mx);
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t maxes[2];
-  SHZ_HIP(ctx, hipMemcpyAsync(maxes, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, maxes, mx, 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->max_sid = std::max(t->max_sid, maxes[0]);   // table-wide maxima size the packed vote key
   t->max_off = std::max(t->max_off, maxes[1]);
@@ -410,7 +410,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
       // the active rows are already in order (the packing is monotone in (key, sid, off)): sort only the new rows and
       // merge the two runs -- one pass over the segment instead of a radix sort of all of it
       SHZ_TRY(shz_sort_u64(ctx, ka + t->n, kb + t->n, nullptr, nullptr, 0, ns, 0, 32 + sb + ob, &sel));
-      if (sel) SHZ_HIP(ctx, hipMemcpyAsync(ka + t->n, kb + t->n, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      if (sel) SHZ_HIP(ctx, shz_memcpy(ctx, ka + t->n, kb + t->n, ns * 8, hipMemcpyDeviceToDevice));
       hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((total + MERGE_TILE - 1) / MERGE_TILE)), dim3(256), 0, ctx->stream,
                          (const uint64_t*)ka, t->n, (const uint64_t*)(ka + t->n), ns, kb);
       SHZ_HIP(ctx, hipGetLastError());
@@ -451,7 +451,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, total, (uint64_t*)tot));
   uint64_t nu = 0;
-  SHZ_HIP(ctx, hipMemcpyAsync(&nu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, &nu, tot, 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // The old columns are dead once composed.  If they can hold the merged rows they are written in place (no
   // hipFree / hipMalloc of gigabytes per finalize: that, not the kernels, dominated incremental ingest); otherwise they
@@ -479,7 +479,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
                        noff);
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t last_key = 0;
-  SHZ_HIP(ctx, hipMemcpyAsync(&last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, &last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->n = nu;
   t->nbuckets = (uint64_t)(last_key >> 8) + 1;
@@ -540,7 +540,7 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
         SHZ_HIP(ctx, hipGetLastError());
         SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, t->ns, (uint64_t*)tot));
         uint64_t cnt = 0;
-        SHZ_HIP(ctx, hipMemcpyAsync(&cnt, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SHZ_HIP(ctx, shz_memcpy(ctx, &cnt, tot, 8, hipMemcpyDeviceToHost));
         SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (cnt == 0) continue;
         SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, cnt * 4, &ck));
@@ -596,9 +596,9 @@ extern "C" int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   uint64_t pos = 0;
   for (const shz_seg& g : all_segs(t)) {  // segment after segment; rows are sorted inside a segment
-    SHZ_HIP(ctx, hipMemcpyAsync(key32 + pos, g.key, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(sid + pos, g.sid, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(off + pos, g.off, g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, key32 + pos, g.key, g.n * 4, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, sid + pos, g.sid, g.n * 4, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, off + pos, g.off, g.n * 4, hipMemcpyDeviceToHost));
     pos += g.n;
   }
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -619,7 +619,7 @@ extern "C" int32_t shz_table_song_rows(shz_table* t, uint32_t sid, uint64_t* n_r
     hipLaunchKernelGGL(tbl_count_sid_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)g.sid, g.n, sid, (unsigned long long*)d);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_HIP(ctx, hipMemcpyAsync(n_rows, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, n_rows, d, 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -672,14 +672,14 @@ static int32_t lookup_segment(shz_table* t, const shz_seg& g, const uint32_t* ke
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (n_keys + 1) * 8, &dcnt));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (n_keys + 1) * 8, &dpo));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &tot));
-  SHZ_HIP(ctx, hipMemcpyAsync(dk, keys, n_keys * 4, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, dk, keys, n_keys * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(tbl_lookup_count_kernel, dim3((unsigned)((n_keys + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                      (const uint32_t*)dk, n_keys, (const uint32_t*)g.key, (uint32_t)g.n, (const uint32_t*)g.bucket,
                      g.nbuckets, (uint32_t*)dlo, (uint64_t*)dcnt);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)dcnt, (uint64_t*)dpo, n_keys + 1, (uint64_t*)tot));
   po_.resize(n_keys + 1);
-  SHZ_HIP(ctx, hipMemcpyAsync(po_.data(), dpo, (n_keys + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, po_.data(), dpo, (n_keys + 1) * 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t total = po_[n_keys];
   ok_.resize(total); os_.resize(total); oo_.resize(total);
@@ -692,9 +692,9 @@ static int32_t lookup_segment(shz_table* t, const shz_seg& g, const uint32_t* ke
                      (const uint32_t*)dlo, (const uint64_t*)dpo, n_keys, total, (const uint32_t*)g.key,
                      (const uint32_t*)g.sid, (const uint32_t*)g.off, (uint32_t*)ok, (uint32_t*)os, (uint32_t*)oo);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_HIP(ctx, hipMemcpyAsync(ok_.data(), ok, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(os_.data(), os, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(oo_.data(), oo, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, ok_.data(), ok, total * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, os_.data(), os, total * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, oo_.data(), oo, total * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -743,10 +743,10 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
   void* d_cnt;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
   uint64_t mine = t->ns;
-  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_cnt, &mine, 8, hipMemcpyHostToDevice));
   SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
   std::vector<uint64_t> cnt(nranks);
-  SHZ_HIP(ctx, hipMemcpyAsync(cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint64_t total = 0;
   std::vector<uint64_t> displ(nranks), bytes(nranks);
@@ -1436,7 +1436,7 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));
   uint64_t G64 = 0;
-  SHZ_HIP(ctx, hipMemcpyAsync(&G64, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, &G64, d_tot, 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipMemsetAsync(qstart, 0xFF, (uint64_t)nq * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(long_cnt, 0, 4, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1489,7 +1489,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   const int nseg = (int)hsegs.size();
   void* d_segs;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, sizeof(shz_seg_dev) * SHZ_MAX_SEGS, &d_segs));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_segs, hsegs.data(), sizeof(shz_seg_dev) * nseg, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_segs, hsegs.data(), sizeof(shz_seg_dev) * nseg, hipMemcpyHostToDevice));
   m_bits mb;
   mb.sb = bits_for(t->max_sid);
   mb.dbits = 0;
@@ -1501,8 +1501,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     void *a, *b;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, h1 * 4, &a));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, h1 * 4, &b));
-    SHZ_HIP(ctx, hipMemcpyAsync(a, key32, h1 * 4, hipMemcpyHostToDevice, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(b, q_off, h1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, a, key32, h1 * 4, hipMemcpyHostToDevice));
+    SHZ_HIP(ctx, shz_memcpy(ctx, b, q_off, h1 * 4, hipMemcpyHostToDevice));
     d_key = (const uint32_t*)a;
     d_qo = (const uint32_t*)b;
   }
@@ -1518,7 +1518,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     mb.qb = bits_for(nq - 1);
     void *d_qoff, *c0, *c1, *fl, *ps, *tot, *err;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
-    SHZ_HIP(ctx, hipMemcpyAsync(d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &tot));
     err = (char*)tot + 128;
     SHZ_HIP(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
@@ -1552,8 +1552,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_HIP(ctx, hipGetLastError());
     uint64_t mu = 0;
     uint32_t herr[3] = {0, 0, 0};
-    SHZ_HIP(ctx, hipMemcpyAsync(&mu, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(herr, err, 12, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, &mu, tot, 8, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, herr, err, 12, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (herr[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
     if (herr[2] < m) --mu;  // the filler element of the hashes other shards own sorts last: drop it
@@ -1581,7 +1581,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                        (uint32_t*)fl);
     SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, mu, (uint64_t*)tot + 1));
     uint64_t ng64 = 0;
-    SHZ_HIP(ctx, hipMemcpyAsync(&ng64, (uint64_t*)tot + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, &ng64, (uint64_t*)tot + 1, 8, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t ng = (uint32_t)ng64;
     const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
@@ -1601,8 +1601,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_HIP(ctx, hipGetLastError());
     SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx + 1, (uint64_t*)tot + 3));
     uint64_t P = 0, rows_total = 0;
-    SHZ_HIP(ctx, hipMemcpyAsync(&P, (uint64_t*)tot + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(&rows_total, (uint64_t*)tot + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, shz_memcpy(ctx, &P, (uint64_t*)tot + 3, 8, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, &rows_total, (uint64_t*)tot + 2, 8, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (P > P_BUDGET && nq > 1) {  // too many pairs for one pass: retry with fewer queries
       step = std::max<uint32_t>(1, nq / 2);
@@ -1619,8 +1619,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
                        (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, (uint32_t*)d_nh, (uint64_t*)d_np);
     SHZ_HIP(ctx, hipGetLastError());
-    if (out_nhash) SHZ_HIP(ctx, hipMemcpyAsync(out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_npairs) SHZ_HIP(ctx, hipMemcpyAsync(out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_nhash) SHZ_HIP(ctx, shz_memcpy(ctx, out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost));
+    if (out_npairs) SHZ_HIP(ctx, shz_memcpy(ctx, out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost));
     // device result buffers
     void *r_sid = nullptr, *r_delta = nullptr, *r_al = nullptr, *r_dd = nullptr, *r_n = nullptr;
     const uint64_t nres = (uint64_t)nq * topn;
@@ -1666,11 +1666,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     }
     if (!vs_out) {
       const uint64_t o0 = (uint64_t)q0 * topn;
-      SHZ_HIP(ctx, hipMemcpyAsync(out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipMemcpyAsync(out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipMemcpyAsync(out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipMemcpyAsync(out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-      SHZ_HIP(ctx, hipMemcpyAsync(out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, shz_memcpy(ctx, out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost));
     }
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     q0 += nq;
@@ -1754,7 +1754,7 @@ static int32_t stage_select_shard(shz_table* t, uint32_t nsh, uint32_t want, uin
                      (const uint32_t*)t->ssid, (const uint32_t*)t->soff, (const uint32_t*)fl, (const uint32_t*)ps, t->ns, ok,
                      os, oo);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_HIP(ctx, hipMemcpyAsync(cnt, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, cnt, tot, 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -1804,7 +1804,7 @@ static int32_t stage_partition(shz_table* t, uint32_t nsh, uint32_t* ok, uint32_
                      (const uint64_t*)(sel ? k1 : k0), (const uint64_t*)(sel ? v1 : v0), ns, ok, os, oo, (unsigned long long*)st);
   SHZ_HIP(ctx, hipGetLastError());
   std::vector<uint64_t> start(nsh);
-  SHZ_HIP(ctx, hipMemcpyAsync(start.data(), st, 8ull * nsh, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, start.data(), st, 8ull * nsh, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint64_t next = ns;  // shards without rows start where the next one does
   for (int d = (int)nsh - 1; d >= 0; --d) {
@@ -1830,7 +1830,7 @@ extern "C" int32_t shz_table_keep_shard(shz_table* t, uint32_t shard, uint32_t n
   const uint64_t kept = cnt[shard];
   uint32_t* dst[3] = {t->skey, t->ssid, t->soff};                      // the staged columns are big enough
   for (int i = 0; i < 3; ++i)
-    if (kept) SHZ_HIP(ctx, hipMemcpyAsync(dst[i], g.p[i] + first, kept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (kept) SHZ_HIP(ctx, shz_memcpy(ctx, dst[i], g.p[i] + first, kept * 4, hipMemcpyDeviceToDevice));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->ns = kept;
   return SHZ_OK;
@@ -1853,10 +1853,10 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   // 2) everyone learns the whole count matrix: row r = what rank r sends to each destination
   void* d_cnt;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * nranks * (nranks + 1), &d_cnt));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, scnt.data(), 8ull * nranks, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_cnt, scnt.data(), 8ull * nranks, hipMemcpyHostToDevice));
   SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + nranks, 8ull * nranks));
   std::vector<uint64_t> mat((size_t)nranks * nranks);
-  SHZ_HIP(ctx, hipMemcpyAsync(mat.data(), (uint64_t*)d_cnt + nranks, 8ull * nranks * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, mat.data(), (uint64_t*)d_cnt + nranks, 8ull * nranks * nranks, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<uint64_t> rcnt(nranks), rdis(nranks);
   uint64_t total = 0;
@@ -1884,10 +1884,10 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   // every shard packs its votes in one layout: agree on the largest song id / offset of the whole table
   uint32_t mx[2] = {t->max_sid, t->max_off};
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, mx, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_cnt, mx, 8, hipMemcpyHostToDevice));
   SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
   std::vector<uint32_t> all(2 * (size_t)nranks);
-  SHZ_HIP(ctx, hipMemcpyAsync(all.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, all.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int r = 0; r < nranks; ++r) {
     t->max_sid = std::max(t->max_sid, all[2 * r]);
@@ -1906,10 +1906,10 @@ extern "C" int32_t shz_pairs_allgather(shz_comm* c, uint64_t n_local, const uint
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void* d_cnt;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d_cnt));
-  SHZ_HIP(ctx, hipMemcpyAsync(d_cnt, &n_local, 8, hipMemcpyHostToDevice, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_cnt, &n_local, 8, hipMemcpyHostToDevice));
   SHZ_TRY(shz_comm_allgather_bytes(c, d_cnt, (uint64_t*)d_cnt + 1, 8));
   std::vector<uint64_t> cnt(nranks), bytes(nranks), displ(nranks);
-  SHZ_HIP(ctx, hipMemcpyAsync(cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, cnt.data(), (uint64_t*)d_cnt + 1, 8ull * nranks, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint64_t total = 0;
   for (int r = 0; r < nranks; ++r) { displ[r] = total * 8; bytes[r] = cnt[r] * 8; total += cnt[r]; }
@@ -1954,11 +1954,11 @@ extern "C" int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, u
   SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)n_queries * 4, ctx->stream));
   SHZ_TRY(vote_tail(ctx, d_pairs, (uint64_t*)v1, n, n_queries, mb, topn, (uint64_t*)tot, (uint32_t*)r_sid, (int32_t*)r_delta,
                     (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
-  SHZ_HIP(ctx, hipMemcpyAsync(out_sid, r_sid, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(out_delta, r_delta, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(out_aligned, r_al, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(out_dedup, r_dd, nres * 4, hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(out_nres, r_n, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_sid, r_sid, nres * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_delta, r_delta, nres * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_aligned, r_al, nres * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_dedup, r_dd, nres * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_nres, r_n, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
