@@ -97,12 +97,21 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
   // The loads of frame g + gridDim are issued BEFORE frame g's output stores: vmcnt retires in
   // order, so loads issued behind the stores would wait for the stores' HBM acknowledgements.
   int pw[8];
+  uint32_t clip = 0xFFFFFFFFu;  // clip of the frame loaded last: a workgroup's frames ascend, so the next one is near
   auto issue_loads = [&](uint32_t g) {
-    uint32_t lo = 0, hi = a.n_clips;  // clip of frame g (uniform binary search over the frame offsets)
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (a.clip_foff[mid] <= g) lo = mid; else hi = mid;
+    uint32_t lo;
+    if (clip == 0xFFFFFFFFu) {  // first frame: uniform binary search over the frame offsets
+      lo = 0;
+      uint32_t hi = a.n_clips;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a.clip_foff[mid] <= g) lo = mid; else hi = mid;
+      }
+    } else {                    // later frames: walk on from the last clip (one or two scalar loads, not ten in a chain)
+      lo = clip;
+      while (lo + 1 < a.n_clips && a.clip_foff[lo + 1] <= g) ++lo;
     }
+    clip = lo;
     const uint64_t clen = a.clip_len[lo];
     const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * SHZ_HOP;
     const int16_t* src = a.pcm + a.clip_soff[lo] + s_in_clip;
@@ -517,17 +526,31 @@ __global__ void gather_offsets_kernel(const uint32_t* __restrict__ scan, const u
   out[c] = (c == n_clips || idx >= n_elems) ? (uint32_t)*total : scan[idx];
 }
 
+// clip of peak i: the workgroup's first peak is searched once (peaks are clip-major), every thread walks on from there
+__device__ __forceinline__ uint32_t pair_clip_of(const uint32_t* __restrict__ peak_coff, uint32_t n_clips, uint32_t i) {
+  __shared__ uint32_t s_lo;
+  if (threadIdx.x == 0) {
+    const uint32_t first = blockIdx.x * blockDim.x;
+    uint32_t lo = 0, hi = n_clips;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (peak_coff[mid] <= first) lo = mid; else hi = mid;
+    }
+    s_lo = lo;
+  }
+  __syncthreads();
+  uint32_t lo = s_lo;
+  while (lo + 1 < n_clips && peak_coff[lo + 1] <= i) ++lo;
+  return lo;
+}
+
 // K4a: number of valid partners of each peak (prefix of the next fan-1 peaks of the same clip with dt <= 200)
 __global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t* __restrict__ peak_t,
                                                          const uint32_t* __restrict__ peak_coff, uint32_t n_clips,
                                                          uint32_t n_peaks, uint32_t fan, uint32_t* __restrict__ cnt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = pair_clip_of(peak_coff, n_clips, i < n_peaks ? i : n_peaks - 1);
   if (i >= n_peaks) return;
-  uint32_t lo = 0, hi = n_clips;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (peak_coff[mid] <= i) lo = mid; else hi = mid;
-  }
   const uint32_t endp = peak_coff[lo + 1];
   const uint32_t t1 = peak_t[i];
   uint32_t c = 0;
@@ -547,12 +570,8 @@ __global__ __launch_bounds__(256) void pair_write_kernel(const uint16_t* __restr
                                                          const uint32_t* __restrict__ hoff, uint32_t* __restrict__ key32,
                                                          uint32_t* __restrict__ t1out, uint64_t out_base, uint64_t cap) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = pair_clip_of(peak_coff, n_clips, i < n_peaks ? i : n_peaks - 1);
   if (i >= n_peaks) return;
-  uint32_t lo = 0, hi = n_clips;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (peak_coff[mid] <= i) lo = mid; else hi = mid;
-  }
   const uint32_t endp = peak_coff[lo + 1];
   const uint32_t t1 = peak_t[i], f1 = peak_f[i];
   uint64_t o = out_base + hoff[i];
