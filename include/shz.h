@@ -38,6 +38,7 @@ extern "C" {
 #define SHZ_PCM_DEVICE 1u    /* pcm pointer is device memory                   */
 #define SHZ_OUT_DEVICE 2u    /* output pointers are device memory              */
 #define SHZ_IN_DEVICE 4u     /* generic: input arrays are device memory        */
+#define SHZ_STFT_POWER 8u    /* shz_stft_db: write the PSD itself, not 10*log10 */
 
 /* constants of the algorithm: __init__.py:41-51 == recognizer.py:21-38 */
 #define SHZ_NFFT 4096
@@ -110,9 +111,17 @@ uint32_t shz_frame_count(uint64_t n_samples);
  *   mlab.specgram(x, NFFT=4096, Fs, window_hanning, noverlap=2048)[0] + 10*log10
  *   (__init__.py:232-241).  clip_off: n_clips+1 sample offsets into pcm (host memory).
  * out_db (HOST): per clip a float64 [2049, F_c] freq-major block (the reference's layout),
- * blocks concatenated in clip order; cap_doubles = capacity of out_db in doubles. */
+ * blocks concatenated in clip order; cap_doubles = capacity of out_db in doubles.
+ * The logarithm is the correctly rounded one (csrc/shz_log10.h).  With SHZ_STFT_POWER the block holds what
+ * specgram returns (the PSD before the log, __init__.py:232-237) in the staged form peak picking reads:
+ * exact zeros read as 1.0, the power whose dB value is the 0.0 the reference assigns them (:241). */
 int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
                     uint32_t fs, uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* count);
+
+/* The log transform alone, on the HOST (no device, no ctx): out_db[i] = 10*log10(power[i]) where power != 0, else 0.0
+ * (__init__.py:241), with the same correctly rounded logarithm the kernels use (csrc/shz_log10.h) -- the function
+ * that decides ties in the peak test, exposed so that tests can pin it without a GPU. */
+int32_t shz_db_values(const double* power, uint64_t n, double* out_db);
 
 /* Constellation peaks of a batch: replaces get_2D_peaks(10*log10(specgram)) +
  * the stable time sort at generate_hashes (__init__.py:116-177, 194-195).

@@ -86,3 +86,34 @@ def mix_query(signal: np.ndarray, noise: np.ndarray, snr_db: float) -> np.ndarra
     rms_cur = math.sqrt(np.mean(nz ** 2))
     nz = nz * (rms_n / rms_cur) if rms_cur > 0 else nz
     return np.clip(np.rint(s + nz), -32768, 32767).astype(np.int16)
+
+
+def lut_tone(n_samples: int, hz_start: float, hz_end: float | None = None, amp: int = 8000) -> np.ndarray:
+    """Integer-only sinusoid / linear chirp from the sine table: phase accumulates omega(n) in 2^-32 turns,
+    omega runs linearly from hz_start to hz_end.  x = (lut[phase >> 20] * amp) >> 15."""
+    lut = sine_lut().astype(np.int64)
+    om0 = int(round(2 ** 32 * hz_start / 44100.0))
+    om1 = om0 if hz_end is None else int(round(2 ** 32 * hz_end / 44100.0))
+    n = np.arange(n_samples, dtype=np.int64)
+    om = om0 + ((om1 - om0) * n) // max(n_samples, 1)
+    ph = np.cumsum(om) & 0xFFFFFFFF
+    return ((lut[ph >> 20] * amp) >> 15).astype(np.int16)
+
+
+def tie_inputs() -> dict:
+    """Near-tie material for the peak predicate (`maximum_filter(A) == A` on dB values, __init__.py:143 after :241):
+    stationary or impulsive signals whose window maxima are shared by cells that differ in the last bits only.
+    Integer-only, so the PCM is the same wherever it is regenerated (digests pinned in tests/golden/tie_cases.npz)."""
+    out = {}
+    x = np.zeros(1323000, np.int16)
+    x[::6161] = 20000
+    out["click_train_30s"] = x
+    out["sine_1k_10s"] = lut_tone(441000, 1000.0)
+    out["two_tone_10s"] = (lut_tone(441000, 440.0, amp=6000).astype(np.int32)
+                           + lut_tone(441000, 1320.0, amp=5000)).astype(np.int16)
+    out["dc_12000_5s"] = np.full(220500, 12000, np.int16)
+    out["chirp_200_4000_10s"] = lut_tone(441000, 200.0, 4000.0)
+    out["tonal_noiseless_10s"] = synth_clip(1234, 21, 441000, 4000, 0)
+    out["sparse_clicks_5s"] = np.zeros(220500, np.int16)
+    out["sparse_clicks_5s"][[30000, 30001, 90000, 150017]] = [32767, -32768, 15000, 9000]
+    return out

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHZ_LIB") or os.path.join(_HERE, "libshz.so")  # SHZ_LIB: A/B builds of the same ABI
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
-PCM_DEVICE, OUT_DEVICE, IN_DEVICE = 1, 2, 4
+PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER = 1, 2, 4, 8
 NFFT, HOP, NBINS = 4096, 2048, 2049
 
 u8p, u16p, u32p, i32p, u64p, i16p, f64p = (C.POINTER(t) for t in (
@@ -43,6 +43,7 @@ SIGNATURES = {
     "shz_sort_pairs": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
+    "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
     "shz_peaks_from_db": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_double, vp, vp, C.c_uint64, u64p]),
     "shz_pair_hash": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -274,12 +275,13 @@ class Context:
         assert co.ndim == 1 and len(co) >= 1
         return co, len(co) - 1
 
-    def stft_db(self, pcm, clip_off, fs=44100, pcm_device=False):
+    def stft_db(self, pcm, clip_off, fs=44100, pcm_device=False, power=False):
         co, nc = self._clip_off(clip_off)
         frames = [int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc)]
         out = np.empty(sum(frames) * NBINS, np.float64)
         cnt = C.c_uint64()
-        self.check(lib().shz_stft_db(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs, PCM_DEVICE if pcm_device else 0,
+        self.check(lib().shz_stft_db(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs,
+                                     (PCM_DEVICE if pcm_device else 0) | (STFT_POWER if power else 0),
                                      ptr(out), out.size, C.byref(cnt)))
         res, pos = [], 0
         for f in frames:

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "shz_internal.h"
+#include "shz_log10.h"
 
 #define DB_STRIDE 2056  // 2049 bins padded so every row starts 64-byte aligned
 
@@ -70,11 +71,13 @@ struct stft_args {
   double scale;                // 0.25 / (Fs * sum(w^2))
 };
 
-// The staged spectrogram holds POWER, not dB: 10*log10 is strictly increasing, so the 21x21
-// max-equality test gives the same cells on P as on 10*log10(P); the log itself is evaluated
-// in peak_pick only for cells that pass it (the `> amp_min` test, __init__.py:161) and in
-// shz_stft_db for the whole array.  Exact-zero power maps to 1.0 because the reference maps it
-// to 0 dB (__init__.py:241), which keeps its rank against sub-unity cells.
+// The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
+// is the dB value of the window's power maximum M -- but it is NOT injective in fp64 (8-37 adjacent doubles of P share
+// one dB value), and the reference tests equality on dB (`maximum_filter(arr2D) == arr2D`, __init__.py:143, after the
+// log at :241).  So peak_pick keeps every cell with P >= M (1 - 2^-40) as a candidate and decides candidates with P != M
+// by the exact comparison 10*log10(P) == 10*log10(M) (shz_log10.h); the log is evaluated nowhere else on the hot
+// path (the `> amp_min` test at :161 needs it only within 1e-9 of the threshold).  Exact-zero power maps to 1.0
+// because the reference maps it to 0 dB (__init__.py:241), which keeps its rank against sub-unity cells.
 __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
   __shared__ cplx lds[2048 + 1025 + 16 + 128];
   cplx* buf = lds;
@@ -274,7 +277,12 @@ struct peak_seg {
 
 // exact threshold test of the reference, `10*log10(P) > amp_min` (__init__.py:161,241), kept out of
 // line: it runs only for local maxima whose power lies within 1e-9 of the threshold
-__device__ __noinline__ bool db_above(double p, double amp_min) { return 10.0 * log10(p) > amp_min; }
+__device__ __noinline__ bool db_above(double p, double amp_min) { return shz_db_of(p) > amp_min; }
+// exact tie test of the reference: the cell's dB value equals the window's dB maximum (__init__.py:143 on the
+// array of :241).  Out of line: runs only for cells within 2^-40 of their window's power maximum M that are not M.
+__device__ __noinline__ bool db_equal(double p, double m) { return shz_db_of(p) == shz_db_of(m); }
+// candidates of the tie test: p >= m (1 - 2^-40).  A dB tie needs p within ~40 ulp of m; 2^-40 is 8192 ulp.
+#define PK_TIE 0.99999999999909050530  /* 1 - 2^-40 */
 
 // --- LDS reads of peak_pick as explicit single ds_read_b64 (see the comment at their use) ---
 typedef __attribute__((address_space(3))) const double pk_lds_cd;
@@ -401,17 +409,24 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
         const int t = tb + u;
         R = (u == 0) ? m1[i] : fmax(R, m1[i]);
         cur[u] = m1[i];
-        if (v[i] == m1[i]) fc |= 1u << u;
+        // POWER: flags mark candidates of the dB tie test (value within 2^-40 of the maximum), decided below
+        if (POWER ? v[i] >= m1[i] * PK_TIE : v[i] == m1[i]) fc |= 1u << u;
         const double m2 = (u < 20) ? fmax(prevS[(u + 1) % 21], R) : R;
+        const double m2c = POWER ? m2 * PK_TIE : m2;
         // centre frame t - 10: position u-10 of the current block or u+11 of the previous one
         bool cand;
-        if (u >= 10) cand = ((fc >> ((u + 11) % 21)) & 1u) && cur[(u + 11) % 21] == m2;
-        else cand = ((fp >> ((u + 11) % 21)) & 1u) && ((sp >> ((u + 11) % 21)) & 1u) && prevS[(u + 11) % 21] == m2;
+        if (u >= 10) cand = ((fc >> ((u + 11) % 21)) & 1u) && cur[(u + 11) % 21] >= m2c;
+        else cand = ((fp >> ((u + 11) % 21)) & 1u) && ((sp >> ((u + 11) % 21)) & 1u) && prevS[(u + 11) % 21] >= m2c;
         const int tc = t - 10;
         const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
         bool pk = is_out && in_seg && cand;
-        if (POWER) {  // power > p_hi: surely above amp_min dB; <= p_lo: surely not; between: exact test
-          if (pk) pk = m2 > p_hi || (m2 > p_lo && db_above(m2, amp_min));
+        if (POWER) {
+          if (pk) {  // a few cells per frame: reload the centre value, which the streaming part does not keep
+            const double vc = src[(uint64_t)tc * row_stride];
+            pk = (vc == m2 || db_equal(vc, m2)) &&
+                 // power > p_hi: surely above amp_min dB; <= p_lo: surely not; between: exact test (dB(vc) == dB(m2))
+                 (m2 > p_hi || (m2 > p_lo && db_above(m2, amp_min)));
+          }
         } else {
           pk = pk && (m2 > amp_min);
         }
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
           prevS[20] = cur[20];
 #pragma unroll
           for (int k = 19; k >= 0; --k) {
-            if (cur[k] >= prevS[k + 1]) sp |= 1u << k;
+            if (cur[k] >= (POWER ? prevS[k + 1] * PK_TIE : prevS[k + 1])) sp |= 1u << k;
             prevS[k] = fmax(cur[k], prevS[k + 1]);
           }
         }
@@ -590,13 +605,14 @@ __global__ __launch_bounds__(256) void pair_write_kernel(const uint16_t* __restr
 
 // transpose [F][stride] (frame-major) -> [n_bins][F] (the reference's freq-major layout)
 __global__ void transpose_db_kernel(const double* __restrict__ in, uint32_t stride, uint32_t F, uint32_t n_bins,
-                                    double* __restrict__ out) {
+                                    double* __restrict__ out, bool as_power) {
   __shared__ double tile[32][33];
   const uint32_t bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: bins, by: frames
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     uint32_t f = by + r, b = bx + threadIdx.x;
     // the staged value is power with zeros stored as 1.0: 10*log10 gives the reference's dB (0 dB for zeros)
-    tile[r][threadIdx.x] = (f < F && b < n_bins) ? 10.0 * log10(in[(uint64_t)f * stride + b]) : 0.0;
+    const double p = (f < F && b < n_bins) ? in[(uint64_t)f * stride + b] : 1.0;
+    tile[r][threadIdx.x] = as_power ? p : shz_db_of(p);
   }
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -624,6 +640,12 @@ __global__ void transpose_in_kernel(const double* __restrict__ in, uint32_t n_ro
 // ======================================================================================
 // host orchestration
 // ======================================================================================
+extern "C" int32_t shz_db_values(const double* power, uint64_t n, double* out_db) {
+  if (n && (!power || !out_db)) return SHZ_E_INVALID;
+  for (uint64_t i = 0; i < n; ++i) out_db[i] = power[i] != 0.0 ? shz_db_of(power[i]) : 0.0;
+  return SHZ_OK;
+}
+
 extern "C" uint32_t shz_frame_count(uint64_t n) {
   if (n < SHZ_NFFT) return 1;
   return (uint32_t)((n - SHZ_NFFT) / SHZ_HOP + 1);
@@ -883,7 +905,7 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
       dim3 grid((SHZ_NBINS + 31) / 32, (F + 31) / 32);
       hipLaunchKernelGGL(transpose_db_kernel, grid, dim3(32, 8), 0, ctx->stream,
                          (const double*)d_db + (uint64_t)sd.foff[i] * DB_STRIDE, (uint32_t)DB_STRIDE, F,
-                         (uint32_t)SHZ_NBINS, (double*)d_tr + tr_pos);
+                         (uint32_t)SHZ_NBINS, (double*)d_tr + tr_pos, (flags & SHZ_STFT_POWER) != 0);
       tr_pos += (uint64_t)F * SHZ_NBINS;
     }
     SHZ_HIP(ctx, hipGetLastError());

@@ -140,8 +140,24 @@ def edge_inputs():
     return cases
 
 
+def tie_cases(ref):
+    """(v) near-tie inputs: the reference's peak test is an equality on dB values, and 10*log10 maps several adjacent
+    doubles of power to one dB value -- these inputs make that visible (stationary tones, clicks, DC)."""
+    tie = {}
+    for name, x in synth.tie_inputs().items():
+        r = run_case(ref, x, 44100)
+        r.pop("col0_db")
+        r["pcm_sha256"] = np.array(sha256(x.tobytes()), dtype="S64")
+        for k, v in r.items():
+            tie[f"{name}_{k}"] = v
+        print(name, int(r["n_frames"]), "frames", len(r["peaks_f"]), "peaks", len(r["hash_hex"]), "hashes")
+    np.savez_compressed(os.path.join(HERE, "tie_cases.npz"), **tie)
+
+
 def main():
     ref = load_reference_extraction()
+    if "--only-ties" in sys.argv:
+        return tie_cases(ref)
     meta = {"numpy": np.__version__}
     import matplotlib
     import scipy
@@ -205,6 +221,8 @@ def main():
         var[f"{tag}_hash_t1"] = np.array([int(o) for _, o in hs], np.int64)
         print("variant", tag, len(hs), "hashes")
     np.savez_compressed(os.path.join(HERE, "param_variants.npz"), **var)
+
+    tie_cases(ref)
 
     # (iv) match / align goldens ---------------------------------------------------------------
     db = StandInDB()
