@@ -150,6 +150,17 @@ int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
                               uint32_t fs, double amp_min, uint32_t fan_value, uint32_t flags,
                               uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count);
 
+/* Staging precision of shz_peaks / shz_fingerprint_batch.  Default (0): the power spectrogram is staged in fp32 and
+ * the cells fp32 cannot decide (shared window maxima, threshold within 1e-7) are re-derived in fp64; results are
+ * those of the fp64 path bit for bit.  1: stage fp64 and decide everything in the peak kernel (twice the HBM traffic;
+ * what a pass falls back to on stationary / plateau material, and always used for amp_min < 0).
+ * Env SHZ_STAGE_F64=1 forces it process-wide. */
+int32_t shz_set_stage_f64(shz_ctx* ctx, int32_t enabled);
+/* Counters since ctx creation: cells left undecided by the fp32 pass, those that needed fp64 values, FFT frames
+ * recomputed for them, passes repeated with fp64 staging. Any pointer may be NULL. */
+int32_t shz_extract_stats(shz_ctx* ctx, uint64_t* undecided, uint64_t* decided_f64, uint64_t* frames_recomputed,
+                          uint64_t* f64_passes);
+
 /* sha1(f"{f1}|{f2}|{dt}")[:10 bytes] per key (__init__.py:207-208; BINARY(10) at
  * mysql_database.py:48).  key32: host or device (SHZ_IN_DEVICE); out10: host [n][10]. */
 int32_t shz_sha1_prefix(shz_ctx* ctx, const uint32_t* key32, uint64_t n, uint32_t flags, uint8_t* out10);

@@ -65,7 +65,8 @@ struct stft_args {
   const uint32_t* clip_foff;   // [n_clips+1] first frame of each clip (sub-batch numbering)
   uint32_t n_clips;
   uint32_t total_frames;
-  double* out;                 // [total_frames][DB_STRIDE] power, exact zeros stored as 1.0 (= 0 dB)
+  void* out;                   // [total_frames][stride] power (f64, stride DB_STRIDE; or f32, stride P32_STRIDE),
+                               // exact zeros stored as 1.0 (= 0 dB)
   const double* window;        // [4096]
   const cplx* tw;              // [1025] W4096^k
   double scale;                // 0.25 / (Fs * sum(w^2))
@@ -74,29 +75,182 @@ struct stft_args {
 // The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
 // is the dB value of the window's power maximum M -- but it is NOT injective in fp64 (8-37 adjacent doubles of P share
 // one dB value), and the reference tests equality on dB (`maximum_filter(arr2D) == arr2D`, __init__.py:143, after the
-// log at :241).  So peak_pick keeps every cell with P >= M (1 - 2^-40) as a candidate and decides candidates with P != M
+// log at :241).  So peak picking keeps every cell close to M as a candidate and decides candidates with P != M
 // by the exact comparison 10*log10(P) == 10*log10(M) (shz_log10.h); the log is evaluated nowhere else on the hot
 // path (the `> amp_min` test at :161 needs it only within 1e-9 of the threshold).  Exact-zero power maps to 1.0
 // because the reference maps it to 0 dB (__init__.py:241), which keeps its rank against sub-unity cells.
-__global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
-  __shared__ cplx lds[2048 + 1025 + 16 + 128];
+//
+// Default staging is fp32 (P32_STRIDE floats per frame): rounding to fp32 is monotone, so a cell that alone holds
+// the fp32 maximum of its window holds the fp64 maximum too, and a cell more than one fp32 step below it cannot tie
+// with it in dB.  What fp32 cannot decide -- cells that share the top two fp32 steps of their window, cells within
+// 1e-7 of the amp_min threshold -- goes to peak_verify_kernel, which recomputes the fp64 values of just those cells
+// with the arithmetic of this kernel (stft_frame below is the one definition of it).
+
+#define LDS_CPLX (2048 + 1025 + 16 + 128)
+
+// twiddle tables into LDS (tw: W4096^k, k <= 1024; tw2/tw3: contiguous copies for passes 2 and 3, no bank conflicts)
+__device__ __forceinline__ void stft_tables(cplx* lds, const cplx* gtw, int j, int nthreads) {
+  cplx* tw = lds + 2048;
+  cplx* tw2 = tw + 1025;
+  cplx* tw3 = tw2 + 16;
+  for (int i = j; i < 1025; i += nthreads) tw[i] = gtw[i];
+  if (j < 8) { tw2[j] = gtw[64 * j]; tw2[8 + j] = gtw[128 * j]; }
+  if (j < 64) { tw3[j] = gtw[8 * j]; tw3[64 + j] = gtw[16 * j]; }
+}
+
+// PCM of frame `g` (sub-batch numbering) of clip `lo` as 8 packed sample pairs per thread
+// (lo16 = x[2n], hi16 = x[2n+1], n = j + 256 t)
+__device__ __forceinline__ void stft_load_frame(const stft_args& a, uint32_t lo, uint32_t g, int j, int (&pw)[8]) {
+  const uint64_t clen = a.clip_len[lo];
+  const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * SHZ_HOP;
+  const int16_t* src = a.pcm + a.clip_soff[lo] + s_in_clip;
+  const uint64_t avail = clen > s_in_clip ? clen - s_in_clip : 0;  // samples readable from src
+  if (avail >= SHZ_NFFT && (((uintptr_t)src) & 3) == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pw[t] = reinterpret_cast<const int*>(src)[j + 256 * t];
+  } else if (avail >= SHZ_NFFT) {  // clip starts at an odd sample of the packed PCM buffer
+    int x0[8], x1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      x0[t] = (int)src[2 * (j + 256 * t)];
+      x1[t] = (int)src[2 * (j + 256 * t) + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pw[t] = (x0[t] & 0xFFFF) | (x1[t] << 16);
+  } else {  // zero padding of inputs shorter than one window (mlab:268-271)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint64_t n0 = 2 * (uint64_t)(j + 256 * t);
+      const int x0 = n0 < avail ? (int)src[n0] : 0;
+      const int x1 = n0 + 1 < avail ? (int)src[n0 + 1] : 0;
+      pw[t] = (x0 & 0xFFFF) | (x1 << 16);
+    }
+  }
+}
+
+// One frame: windowed samples v[8] (complex point j + 256 t = samples 2n, 2n+1) -> power of the 2049 bins.
+// `before_out()` runs between the last butterflies and the outputs (the persistent kernel issues the next frame's
+// loads there); `out(k, p)` receives every bin k once with its scaled power p (exact zero already mapped to 1.0).
+// Ends with a barrier: buf may be rewritten on return.
+template <class PRE, class OUT>
+__device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, double scale, PRE&& before_out, OUT&& out) {
   cplx* buf = lds;
-  cplx* tw = lds + 2048;          // W4096^k, k in [0,1024]: pass 4 and the post-pass
-  cplx* tw2 = tw + 1025;          // pass 2: [0..8) = W_64^k, [8..16) = W_64^2k   (contiguous: no bank conflicts)
-  cplx* tw3 = tw2 + 16;           // pass 3: [0..64) = W_512^k, [64..128) = W_512^2k
-  const int j = threadIdx.x;
-  for (int i = j; i < 1025; i += 256) tw[i] = a.tw[i];
-  if (j < 8) { tw2[j] = a.tw[64 * j]; tw2[8 + j] = a.tw[128 * j]; }
-  if (j < 64) { tw3[j] = a.tw[8 * j]; tw3[64 + j] = a.tw[16 * j]; }
-  __syncthreads();
+  const cplx* tw = lds + 2048;
+  const cplx* tw2 = tw + 1025;
+  const cplx* tw3 = tw2 + 16;
   const int sw = (j >> 3) & 7;  // swizzle term of element j + 256 t
+  // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
+  dft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[(8 * j + r) ^ (j & 7)] = v[r];
+  __syncthreads();
+
+  // pass 2: Ns = 8, twiddles W_64^(k t) = W4096^(64 k t)
+  {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
+    __syncthreads();
+    const int k = j & 7;
+    const cplx w1 = tw2[k], w2 = tw2[8 + k];
+    const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
+    v[1] = cmul(v[1], w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], cmul(w1, w4));
+    v[6] = cmul(v[6], cmul(w2, w4));
+    v[7] = cmul(v[7], cmul(w3, w4));
+    dft8(v);
+    const int base = ((j >> 3) << 6) + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[(base + 8 * r) ^ r] = v[r];  // ((base + 8r) >> 3) & 7 == r
+    __syncthreads();
+  }
+  // pass 3: Ns = 64, twiddles W_512^(k t) = W4096^(8 k t)
+  {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
+    __syncthreads();
+    const int k = j & 63;
+    const cplx w1 = tw3[k], w2 = tw3[64 + k];
+    const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
+    v[1] = cmul(v[1], w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], cmul(w1, w4));
+    v[6] = cmul(v[6], cmul(w2, w4));
+    v[7] = cmul(v[7], cmul(w3, w4));
+    dft8(v);
+    const int base = ((j >> 6) << 9) + k;
+    const int ks = (k >> 3) & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[(base + 64 * r) ^ ks] = v[r];
+    __syncthreads();
+  }
+  // pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
+  // W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
+  // Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
+  // thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
+  // b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
+  {
+    const int bb = j ? 512 - j : 256;
+    const int swb = (bb >> 3) & 7;
+    cplx A0 = buf[j ^ sw], A1 = buf[(j + 512) ^ sw], A2 = buf[(j + 1024) ^ sw], A3 = buf[(j + 1536) ^ sw];
+    cplx B0 = buf[bb ^ swb], B1 = buf[(bb + 512) ^ swb], B2 = buf[(bb + 1024) ^ swb], B3 = buf[(bb + 1536) ^ swb];
+    {
+      const cplx w1 = tw[2 * j];
+      const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+      A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
+      dft4(A0, A1, A2, A3);
+    }
+    {
+      const cplx w1 = tw[2 * bb];
+      const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+      B1 = cmul(B1, w1); B2 = cmul(B2, w2); B3 = cmul(B3, w3);
+      dft4(B0, B1, B2, B3);
+    }
+    before_out();
+    const double scale2 = scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
+    // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024]
+    auto pair_out = [&](int k, cplx zk, cplx zm) {
+      const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
+      const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
+      const cplx wo = cmul(tw[k], o);
+      const cplx xa = cadd(e, wo), xb = csub(e, wo);
+      const double sc = (k != 0) ? scale2 : scale;  // bin 2048 pairs with k = 0: both unscaled
+      const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
+      const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
+      out(k, (pa != 0.0) ? pa : 1.0);
+      if (k != 1024) out(2048 - k, (pb != 0.0) ? pb : 1.0);
+    };
+    // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
+    // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
+    const bool t0 = j == 0;
+    pair_out(t0 ? 256 : 512 - j, B0, t0 ? B3 : A3);   // ordered so that each pair frees its operands early
+    pair_out(j, A0, t0 ? A0 : B3);
+    pair_out(j + 512, A1, t0 ? A3 : B2);
+    pair_out(t0 ? 768 : 1024 - j, B1, t0 ? B2 : A2);
+    if (t0) pair_out(1024, A2, A2);
+  }
+  __syncthreads();  // buf is rewritten by the next frame's pass 1
+}
+
+#define P32_STRIDE 2064  // floats per fp32 row: 2049 bins padded so every row starts 64-byte aligned
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
+  __shared__ cplx lds[LDS_CPLX];
+  const int j = threadIdx.x;
+  stft_tables(lds, a.tw, j, 256);
+  __syncthreads();
+  constexpr uint32_t STRIDE = sizeof(T) == 8 ? DB_STRIDE : P32_STRIDE;
 
   // the Hann window values this thread multiplies with are the same for every frame: registers
   double2 ww[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.window + 2 * (j + 256 * t));
 
-  // PCM of a frame as 8 packed sample pairs per thread (lo16 = x[2n], hi16 = x[2n+1], n = j + 256 t).
   // The loads of frame g + gridDim are issued BEFORE frame g's output stores: vmcnt retires in
   // order, so loads issued behind the stores would wait for the stores' HBM acknowledgements.
   int pw[8];
@@ -115,31 +269,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
       while (lo + 1 < a.n_clips && a.clip_foff[lo + 1] <= g) ++lo;
     }
     clip = lo;
-    const uint64_t clen = a.clip_len[lo];
-    const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * SHZ_HOP;
-    const int16_t* src = a.pcm + a.clip_soff[lo] + s_in_clip;
-    const uint64_t avail = clen > s_in_clip ? clen - s_in_clip : 0;  // samples readable from src
-    if (avail >= SHZ_NFFT && (((uintptr_t)src) & 3) == 0) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) pw[t] = reinterpret_cast<const int*>(src)[j + 256 * t];
-    } else if (avail >= SHZ_NFFT) {  // clip starts at an odd sample of the packed PCM buffer
-      int x0[8], x1[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        x0[t] = (int)src[2 * (j + 256 * t)];
-        x1[t] = (int)src[2 * (j + 256 * t) + 1];
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) pw[t] = (x0[t] & 0xFFFF) | (x1[t] << 16);
-    } else {  // zero padding of inputs shorter than one window (mlab:268-271)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const uint64_t n0 = 2 * (uint64_t)(j + 256 * t);
-        const int x0 = n0 < avail ? (int)src[n0] : 0;
-        const int x1 = n0 + 1 < avail ? (int)src[n0 + 1] : 0;
-        pw[t] = (x0 & 0xFFFF) | (x1 << 16);
-      }
-    }
+    stft_load_frame(a, lo, g, j, pw);
   };
   // XCD-aware frame map: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch), so each
   // group of gridDim/8 workgroups walks ONE contiguous eighth of the frames and the 50 % overlap of
@@ -155,102 +285,10 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
       v[t] = make_double2((double)(short)(pw[t] & 0xFFFF) * ww[t].x, (double)(pw[t] >> 16) * ww[t].y);
-    // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
-    dft8(v);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) buf[(8 * j + r) ^ (j & 7)] = v[r];
-    __syncthreads();
-
-    // pass 2: Ns = 8, twiddles W_64^(k t) = W4096^(64 k t)
-    {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
-      __syncthreads();
-      const int k = j & 7;
-      const cplx w1 = tw2[k], w2 = tw2[8 + k];
-      const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
-      v[1] = cmul(v[1], w1);
-      v[2] = cmul(v[2], w2);
-      v[3] = cmul(v[3], w3);
-      v[4] = cmul(v[4], w4);
-      v[5] = cmul(v[5], cmul(w1, w4));
-      v[6] = cmul(v[6], cmul(w2, w4));
-      v[7] = cmul(v[7], cmul(w3, w4));
-      dft8(v);
-      const int base = ((j >> 3) << 6) + k;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) buf[(base + 8 * r) ^ r] = v[r];  // ((base + 8r) >> 3) & 7 == r
-      __syncthreads();
-    }
-    // pass 3: Ns = 64, twiddles W_512^(k t) = W4096^(8 k t)
-    {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
-      __syncthreads();
-      const int k = j & 63;
-      const cplx w1 = tw3[k], w2 = tw3[64 + k];
-      const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
-      v[1] = cmul(v[1], w1);
-      v[2] = cmul(v[2], w2);
-      v[3] = cmul(v[3], w3);
-      v[4] = cmul(v[4], w4);
-      v[5] = cmul(v[5], cmul(w1, w4));
-      v[6] = cmul(v[6], cmul(w2, w4));
-      v[7] = cmul(v[7], cmul(w3, w4));
-      dft8(v);
-      const int base = ((j >> 6) << 9) + k;
-      const int ks = (k >> 3) & 7;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) buf[(base + 64 * r) ^ ks] = v[r];
-      __syncthreads();
-    }
-    // pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
-    // W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
-    // Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
-    // thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
-    // b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
-    {
-      const int bb = j ? 512 - j : 256;
-      const int swb = (bb >> 3) & 7;
-      cplx A0 = buf[j ^ sw], A1 = buf[(j + 512) ^ sw], A2 = buf[(j + 1024) ^ sw], A3 = buf[(j + 1536) ^ sw];
-      cplx B0 = buf[bb ^ swb], B1 = buf[(bb + 512) ^ swb], B2 = buf[(bb + 1024) ^ swb], B3 = buf[(bb + 1536) ^ swb];
-      {
-        const cplx w1 = tw[2 * j];
-        const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-        A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
-        dft4(A0, A1, A2, A3);
-      }
-      {
-        const cplx w1 = tw[2 * bb];
-        const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-        B1 = cmul(B1, w1); B2 = cmul(B2, w2); B3 = cmul(B3, w3);
-        dft4(B0, B1, B2, B3);
-      }
-      if (g + gstep < gend) issue_loads(g + gstep);  // in flight across the stores below
-      double* orow = a.out + (uint64_t)g * DB_STRIDE;
-      const double scale2 = a.scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
-      // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024]
-      auto pair_out = [&](int k, cplx zk, cplx zm) {
-        const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
-        const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
-        const cplx wo = cmul(tw[k], o);
-        const cplx xa = cadd(e, wo), xb = csub(e, wo);
-        const double sc = (k != 0) ? scale2 : a.scale;  // bin 2048 pairs with k = 0: both unscaled
-        const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
-        const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
-        orow[k] = (pa != 0.0) ? pa : 1.0;
-        if (k != 1024) orow[2048 - k] = (pb != 0.0) ? pb : 1.0;
-      };
-      // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
-      // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
-      const bool t0 = j == 0;
-      pair_out(t0 ? 256 : 512 - j, B0, t0 ? B3 : A3);   // ordered so that each pair frees its operands early
-      pair_out(j, A0, t0 ? A0 : B3);
-      pair_out(j + 512, A1, t0 ? A3 : B2);
-      pair_out(t0 ? 768 : 1024 - j, B1, t0 ? B2 : A2);
-      if (t0) pair_out(1024, A2, A2);
-    }
-    __syncthreads();  // buf is rewritten by the next frame's pass 1
+    T* orow = reinterpret_cast<T*>(a.out) + (uint64_t)g * STRIDE;
+    stft_frame(
+        v, lds, j, a.scale, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
+        [&](int k, double p) { orow[k] = (T)p; });
   }
 }
 
@@ -279,10 +317,12 @@ struct peak_seg {
 // line: it runs only for local maxima whose power lies within 1e-9 of the threshold
 __device__ __noinline__ bool db_above(double p, double amp_min) { return shz_db_of(p) > amp_min; }
 // exact tie test of the reference: the cell's dB value equals the window's dB maximum (__init__.py:143 on the
-// array of :241).  Out of line: runs only for cells within 2^-40 of their window's power maximum M that are not M.
+// array of :241).  Out of line: runs only for cells within 2^-19 of their window's power maximum M that are not M.
 __device__ __noinline__ bool db_equal(double p, double m) { return shz_db_of(p) == shz_db_of(m); }
-// candidates of the tie test: p >= m (1 - 2^-40).  A dB tie needs p within ~40 ulp of m; 2^-40 is 8192 ulp.
-#define PK_TIE 0.99999999999909050530  /* 1 - 2^-40 */
+// candidates of the tie test: the high words of p and m (sign, exponent, 20 mantissa bits) are equal or adjacent,
+// i.e. p > m (1 - 2^-19).  A dB tie needs p within ~40 ulp of m.  Positive doubles order like their high words, and
+// -inf (the padding) has a negative one; two 32-bit integer operations instead of an fp64 multiply and compare.
+__device__ __forceinline__ bool pk_near(double p, double m) { return __double2hiint(p) >= __double2hiint(m) - 1; }
 
 // --- LDS reads of peak_pick as explicit single ds_read_b64 (see the comment at their use) ---
 typedef __attribute__((address_space(3))) const double pk_lds_cd;
@@ -409,14 +449,18 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
         const int t = tb + u;
         R = (u == 0) ? m1[i] : fmax(R, m1[i]);
         cur[u] = m1[i];
-        // POWER: flags mark candidates of the dB tie test (value within 2^-40 of the maximum), decided below
-        if (POWER ? v[i] >= m1[i] * PK_TIE : v[i] == m1[i]) fc |= 1u << u;
+        // POWER: flags mark candidates of the dB tie test (value within 2^-19 of the maximum), decided below
+        if (POWER ? pk_near(v[i], m1[i]) : v[i] == m1[i]) fc |= 1u << u;
         const double m2 = (u < 20) ? fmax(prevS[(u + 1) % 21], R) : R;
-        const double m2c = POWER ? m2 * PK_TIE : m2;
         // centre frame t - 10: position u-10 of the current block or u+11 of the previous one
         bool cand;
-        if (u >= 10) cand = ((fc >> ((u + 11) % 21)) & 1u) && cur[(u + 11) % 21] >= m2c;
-        else cand = ((fp >> ((u + 11) % 21)) & 1u) && ((sp >> ((u + 11) % 21)) & 1u) && prevS[(u + 11) % 21] >= m2c;
+        if (u >= 10) {
+          const double ck = cur[(u + 11) % 21];
+          cand = ((fc >> ((u + 11) % 21)) & 1u) && (POWER ? pk_near(ck, m2) : ck == m2);
+        } else {
+          const double sk = prevS[(u + 11) % 21];
+          cand = ((fp >> ((u + 11) % 21)) & 1u) && ((sp >> ((u + 11) % 21)) & 1u) && (POWER ? pk_near(sk, m2) : sk == m2);
+        }
         const int tc = t - 10;
         const bool in_seg = tc >= (int)sg.t0 && tc < (int)sg.t1;
         bool pk = is_out && in_seg && cand;
@@ -440,7 +484,7 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
           prevS[20] = cur[20];
 #pragma unroll
           for (int k = 19; k >= 0; --k) {
-            if (cur[k] >= (POWER ? prevS[k + 1] * PK_TIE : prevS[k + 1])) sp |= 1u << k;
+            if (POWER ? pk_near(cur[k], prevS[k + 1]) : cur[k] >= prevS[k + 1]) sp |= 1u << k;
             prevS[k] = fmax(cur[k], prevS[k + 1]);
           }
         }
@@ -449,13 +493,15 @@ __global__ __launch_bounds__(256, 3) void peak_pick_kernel(const double* __restr
   }
 }
 
+#include "shz_peak32.inc"
+
 // amp_min < 0 only: the reference drops local maxima that sit inside a region of exact zeros.  get_2D_peaks marks
 // `local_max != binary_erosion(arr2D == 0, 21x21, border_value=1)` (__init__.py:147-151): a zero-valued cell whose whole
 // 21x21 window (clipped to the clip; outside counts as zero) is zero is a local maximum AND eroded background, the XOR
 // removes it.  For amp_min >= 0 such cells never pass `> amp_min`; below zero they would, so their mask bits are cleared
 // here, before the scan.  ZERO is 0.0 on a dB array and 1.0 on the power array (zero power is stored as 1.0 = 0 dB).
 __global__ __launch_bounds__(256) void peak_zero_plateau_kernel(uint64_t* __restrict__ mask, uint64_t n_words,
-                                                                uint32_t n_slabs, const double* __restrict__ A,
+                                                                mask_geom mg, const double* __restrict__ A,
                                                                 uint32_t row_stride, uint32_t n_bins, double zero,
                                                                 const uint32_t* __restrict__ clip_foff,
                                                                 uint32_t n_clips) {
@@ -463,10 +509,10 @@ __global__ __launch_bounds__(256) void peak_zero_plateau_kernel(uint64_t* __rest
   if (w >= n_words) return;
   const uint64_t m0 = mask[w];
   if (!m0) return;
-  const uint32_t per_frame = n_slabs * 4;
+  const uint32_t per_frame = mg.n_slabs * mg.nw;
   const uint32_t g = (uint32_t)(w / per_frame);
   const uint32_t rem = (uint32_t)(w % per_frame);
-  const uint32_t slab = rem >> 2, wv = rem & 3;
+  const uint32_t slab = rem / mg.nw, wv = rem % mg.nw;
   uint32_t lo = 0, hi = n_clips;
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
@@ -477,7 +523,7 @@ __global__ __launch_bounds__(256) void peak_zero_plateau_kernel(uint64_t* __rest
   while (m) {
     const int b = __ffsll((long long)m) - 1;
     m &= m - 1;
-    const int col = (int)(slab * PK_SW + wv * 63) + b - 10;
+    const int col = (int)(slab * mg.sw + wv * mg.lane_stride) + b - 10;
     const double* centre = A + (uint64_t)g * row_stride + col;
     if (*centre != zero) continue;
     bool all_zero = true;
@@ -510,23 +556,26 @@ __global__ void frame_time_kernel(const uint32_t* __restrict__ clip_foff, uint32
 
 __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __restrict__ mask,
                                                           const uint32_t* __restrict__ word_off, uint32_t n_words,
-                                                          uint32_t n_slabs, const uint32_t* __restrict__ frame_t,
-                                                          uint16_t* __restrict__ peak_f, uint32_t* __restrict__ peak_t) {
+                                                          mask_geom mg, const uint32_t* __restrict__ frame_t,
+                                                          uint16_t* __restrict__ peak_f, uint32_t* __restrict__ peak_t,
+                                                          uint32_t cap) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
   uint64_t m = mask[w];
   if (!m) return;
-  const uint32_t per_frame = n_slabs * 4;
+  const uint32_t per_frame = mg.n_slabs * mg.nw;
   const uint32_t g = w / per_frame;
   const uint32_t rem = w - g * per_frame;
-  const uint32_t slab = rem >> 2, wv = rem & 3;
+  const uint32_t slab = rem / mg.nw, wv = rem % mg.nw;
   const uint32_t t = frame_t[g];
   uint32_t o = word_off[w];
   while (m) {
     const int b = __ffsll((long long)m) - 1;
     m &= m - 1;
-    peak_f[o] = (uint16_t)(slab * PK_SW + wv * 63 + b - 10);  // wave wv, lane b holds slab column 63 wv + b - 10
-    peak_t[o] = t;
+    if (o < cap) {  // a list too small for the sub-batch is reported through xctl (XF_PEAK_CAP), never overrun
+      peak_f[o] = (uint16_t)(slab * mg.sw + wv * mg.lane_stride + b - 10);  // wave wv, lane b holds that slab column
+      peak_t[o] = t;
+    }
     ++o;
   }
 }
@@ -534,11 +583,12 @@ __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __rest
 // per-clip CSR offsets from a per-element exclusive scan: out[c] = scan[first[c]*mult] (or total at the end)
 __global__ void gather_offsets_kernel(const uint32_t* __restrict__ scan, const uint64_t* __restrict__ total,
                                       const uint32_t* __restrict__ first, uint64_t mult, uint64_t n_elems,
-                                      uint32_t n_clips, uint32_t* __restrict__ out) {
+                                      uint32_t n_clips, uint32_t* __restrict__ out, uint32_t clamp) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > n_clips) return;
   const uint64_t idx = (uint64_t)first[c] * mult;
-  out[c] = (c == n_clips || idx >= n_elems) ? (uint32_t)*total : scan[idx];
+  const uint32_t v = (c == n_clips || idx >= n_elems) ? (uint32_t)*total : scan[idx];
+  out[c] = v < clamp ? v : clamp;
 }
 
 // clip of peak i: the workgroup's first peak is searched once (peaks are clip-major), every thread walks on from there
@@ -559,13 +609,24 @@ __device__ __forceinline__ uint32_t pair_clip_of(const uint32_t* __restrict__ pe
   return lo;
 }
 
-// K4a: number of valid partners of each peak (prefix of the next fan-1 peaks of the same clip with dt <= 200)
+// K4a: number of valid partners of each peak (prefix of the next fan-1 peaks of the same clip with dt <= 200).
+// The number of peaks is read on the device (d_n, clamped to the list capacity n_cap); slots beyond it count 0.
 __global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t* __restrict__ peak_t,
                                                          const uint32_t* __restrict__ peak_coff, uint32_t n_clips,
-                                                         uint32_t n_peaks, uint32_t fan, uint32_t* __restrict__ cnt) {
+                                                         const unsigned long long* __restrict__ d_n, uint32_t n_cap,
+                                                         uint32_t fan, uint32_t* __restrict__ cnt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long nn = *d_n;
+  const uint32_t n_peaks = nn < n_cap ? (uint32_t)nn : n_cap;
+  if (blockIdx.x * blockDim.x >= n_peaks) {  // whole workgroup beyond the list (uniform)
+    if (i < n_cap) cnt[i] = 0;
+    return;
+  }
   const uint32_t lo = pair_clip_of(peak_coff, n_clips, i < n_peaks ? i : n_peaks - 1);
-  if (i >= n_peaks) return;
+  if (i >= n_peaks) {
+    if (i < n_cap) cnt[i] = 0;
+    return;
+  }
   const uint32_t endp = peak_coff[lo + 1];
   const uint32_t t1 = peak_t[i];
   uint32_t c = 0;
@@ -577,19 +638,24 @@ __global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t* __restr
   cnt[i] = c;
 }
 
-// K4b: write (key32, t1) in (i, j) generation order
+// K4b: write (key32, t1) in (i, j) generation order at out_base0 + *d_base (d_base may be null)
 __global__ __launch_bounds__(256) void pair_write_kernel(const uint16_t* __restrict__ peak_f,
                                                          const uint32_t* __restrict__ peak_t,
                                                          const uint32_t* __restrict__ peak_coff, uint32_t n_clips,
-                                                         uint32_t n_peaks, uint32_t fan,
-                                                         const uint32_t* __restrict__ hoff, uint32_t* __restrict__ key32,
-                                                         uint32_t* __restrict__ t1out, uint64_t out_base, uint64_t cap) {
+                                                         const unsigned long long* __restrict__ d_n, uint32_t n_cap,
+                                                         uint32_t fan, const uint32_t* __restrict__ hoff,
+                                                         uint32_t* __restrict__ key32, uint32_t* __restrict__ t1out,
+                                                         uint64_t out_base0, const unsigned long long* __restrict__ d_base,
+                                                         uint64_t cap) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long nn = *d_n;
+  const uint32_t n_peaks = nn < n_cap ? (uint32_t)nn : n_cap;
+  if (blockIdx.x * blockDim.x >= n_peaks) return;  // uniform
   const uint32_t lo = pair_clip_of(peak_coff, n_clips, i < n_peaks ? i : n_peaks - 1);
   if (i >= n_peaks) return;
   const uint32_t endp = peak_coff[lo + 1];
   const uint32_t t1 = peak_t[i], f1 = peak_f[i];
-  uint64_t o = out_base + hoff[i];
+  uint64_t o = out_base0 + (d_base ? *d_base : 0ull) + hoff[i];
   for (uint32_t jn = 1; jn < fan; ++jn) {
     if (i + jn >= endp) break;
     const uint32_t dt = peak_t[i + jn] - t1;
@@ -602,6 +668,38 @@ __global__ __launch_bounds__(256) void pair_write_kernel(const uint16_t* __restr
     }
   }
 }
+
+// ---- bookkeeping of the device-driven pipeline (xctl, shz_peak32.inc): tiny single-thread kernels ----
+__global__ void xctl_begin_sub_kernel(xctl* c) { c->und_count = 0; }
+// after the popcount scan: was the peak list large enough?
+__global__ void xctl_after_peaks_kernel(xctl* c, uint32_t cap_peaks, uint32_t und_cap) {
+  if (c->sub_peaks > cap_peaks) c->flags |= XF_PEAK_CAP;
+  if (c->sub_peaks > c->max_sub_peaks) c->max_sub_peaks = c->sub_peaks;
+  if (c->und_count > und_cap) c->flags |= XF_UND_CAP | XF_FALLBACK;
+}
+// per-clip output offsets of this sub-batch: out64[c0 + i + 1] = base + rel[i + 1]  (rel clamped by the producer)
+__global__ void xctl_offsets_kernel(const xctl* c, bool hashes, const uint32_t* __restrict__ rel, uint32_t nc,
+                                    uint32_t c0, unsigned long long* __restrict__ out64) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  out64[c0 + i + 1] = (hashes ? c->hash_base : c->peak_base) + rel[i + 1];
+}
+__global__ void xctl_advance_kernel(xctl* c, uint32_t cap_peaks, bool hashes) {
+  c->peak_base += c->sub_peaks < cap_peaks ? c->sub_peaks : cap_peaks;
+  if (hashes) c->hash_base += c->sub_hashes;
+}
+// append this sub-batch's peak list to the output arrays at peak_base
+__global__ __launch_bounds__(256) void peaks_out_kernel(const xctl* c, const uint16_t* __restrict__ pf,
+                                                        const uint32_t* __restrict__ pt, uint32_t cap_peaks,
+                                                        uint16_t* __restrict__ out_f, uint32_t* __restrict__ out_t,
+                                                        uint64_t cap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t n = c->sub_peaks < cap_peaks ? c->sub_peaks : cap_peaks;
+  if (i >= n) return;
+  const uint64_t o = c->peak_base + i;
+  if (o < cap) { out_f[o] = pf[i]; out_t[o] = pt[i]; }
+}
+__global__ void set_u64_dev_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 
 // transpose [F][stride] (frame-major) -> [n_bins][F] (the reference's freq-major layout)
 __global__ void transpose_db_kernel(const double* __restrict__ in, uint32_t stride, uint32_t F, uint32_t n_bins,
@@ -654,14 +752,31 @@ extern "C" uint32_t shz_frame_count(uint64_t n) {
 #define PK_SEG 252       // output frames per peak_pick workgroup (12 blocks of 21) when workgroups are scarce
 #define PK_SEG_LONG 672  // ... and when the batch is large: 32 blocks, a 30 s clip in one piece (no time halo)
 
+static const mask_geom MG_F64 = {(SHZ_NBINS + PK_SW - 1) / PK_SW, 4, 63, PK_SW};
+static mask_geom mg_f32(int nw) {
+  const uint32_t sw = 61u * nw - 17u;
+  return mask_geom{(SHZ_NBINS + sw - 1) / sw, (uint32_t)nw, 61u, sw};
+}
+// waves per peak_pick32 workgroup (slab = 61 nw - 17 bins).  Measured on 644,000 frames: 7 waves (5 slabs) 3.93 ms,
+// 6: 4.47, 4 (10 slabs): 2.65, 3: 2.56, 2 (20 slabs of 105 bins, 19 % halo): 2.05, 1: 2.22 -- small workgroups win
+// although they re-read more halo: the two barriers per 7 frames cost more than the columns
+static int p32_nw() {
+  static const int nw = [] {
+    const char* e = getenv("SHZ_PEAK_NW");
+    const int v = e ? atoi(e) : 2;
+    return (v >= 1 && v <= 7 && v != 5) ? v : 2;
+  }();
+  return nw;
+}
+
 struct sub_batch {
   uint32_t c0, c1;        // clips [c0, c1)
   uint32_t frames;
 };
 
-static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t n_clips,
+static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t n_clips, uint64_t bytes_per_frame,
                                 std::vector<sub_batch>& out) {
-  uint64_t max_frames = ctx->ws_limit / ((uint64_t)DB_STRIDE * 8);
+  uint64_t max_frames = ctx->ws_limit / bytes_per_frame;
   if (max_frames > (1u << 20)) max_frames = 1u << 20;  // mask words, peaks < 2^32 (hash count checked per sub-batch)
   if (max_frames < 64) max_frames = 64;
   sub_batch cur{0, 0, 0};
@@ -692,41 +807,43 @@ struct sub_dev {
   std::vector<uint32_t> foff;
 };
 
-// upload per-clip metadata of a sub-batch; pcm_base_off = sample offset of d_pcm[0] in clip_off units
+// Upload per-clip metadata of a sub-batch; pcm_base_off = sample offset of d_pcm[0] in clip_off units.
+// No host synchronisation: the host-side image of the tables is handed to `keep`, which the caller holds until the
+// call's final sync (a small pageable hipMemcpyAsync may or may not have staged its source when it returns).
 static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_batch& sb, uint64_t pcm_base_off,
-                           sub_dev& sd) {
+                           uint32_t n_slabs, uint32_t wg_per_cu, sub_dev& sd, std::vector<std::vector<uint64_t>>& keep) {
   const uint32_t nc = sb.c1 - sb.c0;
-  std::vector<uint64_t> soff(nc), len(nc);
   sd.foff.assign(nc + 1, 0);
   std::vector<peak_seg> segs;
   // Each segment re-reads 10 halo frames on both sides (PMC: -4.6 % kernel time with whole-clip segments), but short
   // segments keep the chip busy on small batches: go long once that still leaves >= 4 workgroups per slot.
-  const uint64_t slots = (uint64_t)ctx->prop.multiProcessorCount * 3;
-  const uint64_t n_slabs_ = (SHZ_NBINS + PK_SW - 1) / PK_SW;
-  const uint32_t seg_len = (uint64_t)sb.frames * n_slabs_ / PK_SEG_LONG >= 4 * slots ? PK_SEG_LONG : PK_SEG;
+  const uint64_t slots = (uint64_t)ctx->prop.multiProcessorCount * wg_per_cu;
+  const uint32_t seg_len = (uint64_t)sb.frames * n_slabs / PK_SEG_LONG >= 4 * slots ? PK_SEG_LONG : PK_SEG;
+  // one blob: soff[nc] | len[nc] | foff[nc+1] (u32, padded to 8) | segs
+  const uint64_t foff_words = (nc + 2) / 2;  // u64 words holding nc+1 u32
   for (uint32_t i = 0; i < nc; ++i) {
-    const uint32_t c = sb.c0 + i;
-    soff[i] = clip_off[c] - pcm_base_off;
-    len[i] = clip_off[c + 1] - clip_off[c];
-    const uint32_t f = shz_frame_count(len[i]);
+    const uint32_t f = shz_frame_count(clip_off[sb.c0 + i + 1] - clip_off[sb.c0 + i]);
     sd.foff[i + 1] = sd.foff[i] + f;
     for (uint32_t t0 = 0; t0 < f; t0 += seg_len)
       segs.push_back(peak_seg{sd.foff[i], f, t0, std::min(t0 + seg_len, f)});
   }
-  void *p0, *p1;
-  const uint64_t meta_bytes = (uint64_t)nc * 16 + (uint64_t)(nc + 1) * 4 + 64;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, meta_bytes, &p0));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META2, segs.size() * sizeof(peak_seg) + 64, &p1));
+  static_assert(sizeof(peak_seg) == 16, "peak_seg is two u64 words");
+  keep.emplace_back(2 * (uint64_t)nc + foff_words + 2 * segs.size() + 1);
+  std::vector<uint64_t>& blob = keep.back();
+  for (uint32_t i = 0; i < nc; ++i) {
+    blob[i] = clip_off[sb.c0 + i] - pcm_base_off;
+    blob[nc + i] = clip_off[sb.c0 + i + 1] - clip_off[sb.c0 + i];
+  }
+  memcpy(&blob[2 * (uint64_t)nc], sd.foff.data(), (nc + 1) * 4);
+  if (!segs.empty()) memcpy(&blob[2 * (uint64_t)nc + foff_words], segs.data(), segs.size() * sizeof(peak_seg));
+  void* p0;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, blob.size() * 8 + 64, &p0));
   sd.d_soff = (uint64_t*)p0;
   sd.d_len = sd.d_soff + nc;
   sd.d_foff = (uint32_t*)(sd.d_len + nc);
-  sd.d_segs = (peak_seg*)p1;
+  sd.d_segs = (peak_seg*)(sd.d_soff + 2 * (uint64_t)nc + foff_words);
   sd.n_segs = (uint32_t)segs.size();
-  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_soff, soff.data(), nc * 8, hipMemcpyHostToDevice));
-  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_len, len.data(), nc * 8, hipMemcpyHostToDevice));
-  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_foff, sd.foff.data(), (nc + 1) * 4, hipMemcpyHostToDevice));
-  SHZ_HIP(ctx, shz_memcpy(ctx, sd.d_segs, segs.data(), segs.size() * sizeof(peak_seg), hipMemcpyHostToDevice));
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  SHZ_HIP(ctx, shz_memcpy(ctx, p0, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
   return SHZ_OK;
 }
 
@@ -747,9 +864,8 @@ static int32_t stage_pcm(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_
   return SHZ_OK;
 }
 
-static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd, uint32_t nc, uint32_t frames,
-                           uint32_t fs, double* d_db) {
-  shz_prof_scope ps(ctx, 0);
+static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd, uint32_t nc, uint32_t frames,
+                                uint32_t fs, void* d_out) {
   stft_args a;
   a.pcm = d_pcm;
   a.clip_soff = sd.d_soff;
@@ -757,47 +873,63 @@ static int32_t launch_stft(shz_ctx* ctx, const int16_t* d_pcm, const sub_dev& sd
   a.clip_foff = sd.d_foff;
   a.n_clips = nc;
   a.total_frames = frames;
-  a.out = d_db;
+  a.out = d_out;
   a.window = ctx->d_window;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
+  return a;
+}
+
+template <typename T>
+static int32_t launch_stft(shz_ctx* ctx, const stft_args& a) {
+  shz_prof_scope ps(ctx, 0);
   static const int wgs_per_cu = [] {  // tuning knob: resident stft workgroups per CU (LDS allows 3)
     const char* e = getenv("SHZ_STFT_WGS_PER_CU");
     const int v = e ? atoi(e) : 3;
     return v >= 1 && v <= 3 ? v : 3;
   }();
   uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * wgs_per_cu;
-  if (grid > frames) grid = frames;
+  if (grid > a.total_frames) grid = a.total_frames;
   grid = (grid + 7) & ~7u;  // multiple of 8: see the XCD-aware frame map in the kernel
-  hipLaunchKernelGGL(stft_psd_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(stft_psd_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, a);
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
 
-// peaks of a frame-major dB buffer -> device peak list (ws PEAK_F / PEAK_T) + per-clip offsets (ws PEAK_CLIP)
+// fp64 threshold band around amp_min (power domain): above p_hi surely `> amp_min` dB, at or below p_lo surely not
+static void threshold_band(double amp_min, double* p_lo, double* p_hi) {
+  const double thr = pow(10.0, amp_min / 10.0);
+  *p_lo = thr * (1.0 - 1e-9);
+  *p_hi = thr * (1.0 + 1e-9);
+}
+
+// peaks of a frame-major fp64 buffer -> device peak list (ws PEAK_F / PEAK_T) + per-clip offsets (ws PEAK_CLIP).
+// Host-synchronous helper of the stage APIs (shz_peaks_from_db); the batch path is extract_pass below.
 static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, uint32_t n_bins, const sub_dev& sd,
                          uint32_t nc, uint32_t frames, double amp_min, bool is_power, uint16_t** d_pf, uint32_t** d_pt,
                          uint32_t** d_pcoff, uint32_t* n_peaks) {
-  const uint32_t n_slabs = (n_bins + PK_SW - 1) / PK_SW;
-  const uint64_t n_words = (uint64_t)frames * n_slabs * 4;
+  mask_geom mg = MG_F64;
+  mg.n_slabs = (n_bins + PK_SW - 1) / PK_SW;
+  const uint64_t n_words = (uint64_t)frames * mg.n_slabs * 4;
   void *d_mask, *d_woff, *d_tot;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MASK, n_words * 8, &d_mask));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, n_words * 4, &d_woff));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &d_tot));
+  double p_lo, p_hi;
+  threshold_band(amp_min, &p_lo, &p_hi);
   {
     shz_prof_scope ps(ctx, 1);
     if (is_power)
-      hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
-                         n_bins, sd.d_segs, n_slabs, amp_min, pow(10.0, amp_min / 10.0) * (1.0 - 1e-9),
-                         pow(10.0, amp_min / 10.0) * (1.0 + 1e-9), (uint64_t*)d_mask);
+      hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(mg.n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
+                         n_bins, sd.d_segs, mg.n_slabs, amp_min, p_lo, p_hi, (uint64_t*)d_mask);
     else
-      hipLaunchKernelGGL(peak_pick_kernel<false>, dim3(n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
-                         n_bins, sd.d_segs, n_slabs, amp_min, 0.0, 0.0, (uint64_t*)d_mask);
+      hipLaunchKernelGGL(peak_pick_kernel<false>, dim3(mg.n_slabs, sd.n_segs), dim3(256), 0, ctx->stream, d_db, row_stride,
+                         n_bins, sd.d_segs, mg.n_slabs, amp_min, 0.0, 0.0, (uint64_t*)d_mask);
     SHZ_HIP(ctx, hipGetLastError());
   }
   if (amp_min < 0.0 && n_words) {  // see peak_zero_plateau_kernel
     hipLaunchKernelGGL(peak_zero_plateau_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (uint64_t*)d_mask, n_words, n_slabs, d_db, row_stride, n_bins, is_power ? 1.0 : 0.0, sd.d_foff, nc);
+                       (uint64_t*)d_mask, n_words, mg, d_db, row_stride, n_bins, is_power ? 1.0 : 0.0, sd.d_foff, nc);
     SHZ_HIP(ctx, hipGetLastError());
   }
   uint64_t tot = 0;
@@ -817,13 +949,13 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
       hipLaunchKernelGGL(frame_time_kernel, dim3((frames + 255) / 256), dim3(256), 0, ctx->stream, sd.d_foff, nc, frames,
                          (uint32_t*)ft);
       hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
-                         (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, n_slabs, (const uint32_t*)ft,
-                         (uint16_t*)pf, (uint32_t*)pt);
+                         (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
+                         (uint16_t*)pf, (uint32_t*)pt, (uint32_t)tot);
       SHZ_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)d_woff, (const uint64_t*)d_tot, sd.d_foff, (uint64_t)n_slabs * 4, n_words, nc,
-                       (uint32_t*)pc);
+                       (const uint32_t*)d_woff, (const uint64_t*)d_tot, sd.d_foff, (uint64_t)mg.n_slabs * 4, n_words, nc,
+                       (uint32_t*)pc, 0xFFFFFFFFu);
     SHZ_HIP(ctx, hipGetLastError());
     *d_pf = (uint16_t*)pf;
     *d_pt = (uint32_t*)pt;
@@ -833,7 +965,7 @@ static int32_t run_peaks(shz_ctx* ctx, const double* d_db, uint32_t row_stride, 
   return SHZ_OK;
 }
 
-// pair hashing of a device peak list; writes into (d_key, d_t1) at out_base (device arrays of capacity cap)
+// pair hashing of a device peak list (host-synchronous helper of shz_pair_hash); writes into (d_key, d_t1)
 static int32_t run_pairs(shz_ctx* ctx, const uint16_t* d_pf, const uint32_t* d_pt, const uint32_t* d_pcoff, uint32_t nc,
                          uint32_t n_peaks, uint32_t fan, uint32_t* d_key, uint32_t* d_t1, uint64_t out_base, uint64_t cap,
                          uint64_t* n_hashes, std::vector<uint32_t>* clip_hoff /* nc+1, relative */) {
@@ -843,22 +975,24 @@ static int32_t run_pairs(shz_ctx* ctx, const uint16_t* d_pf, const uint32_t* d_p
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)n_peaks * 4 + 64, &d_hoff));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &d_tot));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)(nc + 1) * 4 + 64, &d_choff));
+  unsigned long long* d_n = (unsigned long long*)d_tot + 1;
+  hipLaunchKernelGGL(set_u64_dev_kernel, dim3(1), dim3(1), 0, ctx->stream, d_n, (unsigned long long)n_peaks);
   const unsigned nb = (n_peaks + 255) / 256;
   if (n_peaks) {
-    hipLaunchKernelGGL(pair_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pt, d_pcoff, nc, n_peaks, fan,
+    hipLaunchKernelGGL(pair_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pt, d_pcoff, nc, d_n, n_peaks, fan,
                        (uint32_t*)d_cnt);
     SHZ_HIP(ctx, hipGetLastError());
   }
   SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)d_cnt, (uint32_t*)d_hoff, n_peaks, (uint64_t*)d_tot));
   if (n_peaks) {
-    hipLaunchKernelGGL(pair_write_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pf, d_pt, d_pcoff, nc, n_peaks, fan,
-                       (const uint32_t*)d_hoff, d_key, d_t1, out_base, cap);
+    hipLaunchKernelGGL(pair_write_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pf, d_pt, d_pcoff, nc, d_n, n_peaks, fan,
+                       (const uint32_t*)d_hoff, d_key, d_t1, out_base, (const unsigned long long*)nullptr, cap);
     SHZ_HIP(ctx, hipGetLastError());
   }
   // per-clip hash offsets: hoff[pcoff[c]]
   hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                      (const uint32_t*)d_hoff, (const uint64_t*)d_tot, d_pcoff, (uint64_t)1, (uint64_t)n_peaks, nc,
-                     (uint32_t*)d_choff);
+                     (uint32_t*)d_choff, 0xFFFFFFFFu);
   SHZ_HIP(ctx, hipGetLastError());
   uint64_t tot = 0;
   clip_hoff->resize(nc + 1);
@@ -886,7 +1020,8 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   if (count) *count = need;
   if (need > cap_doubles || (need && !out_db)) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_stft_db: need %llu doubles", (unsigned long long)need);
   std::vector<sub_batch> subs;
-  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, subs));
+  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, (uint64_t)DB_STRIDE * 8, subs));
+  std::vector<std::vector<uint64_t>> keep;
   uint64_t out_pos = 0;
   for (const sub_batch& sb : subs) {
     const uint32_t nc = sb.c1 - sb.c0;
@@ -894,10 +1029,10 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
     uint64_t base;
     SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
     sub_dev sd;
-    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, sd));
+    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, MG_F64.n_slabs, 3, sd, keep));
     void *d_db, *d_tr;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * DB_STRIDE * 8, &d_db));
-    SHZ_TRY(launch_stft(ctx, d_pcm, sd, nc, sb.frames, fs, (double*)d_db));
+    SHZ_TRY(launch_stft<double>(ctx, make_stft_args(ctx, d_pcm, sd, nc, sb.frames, fs, d_db)));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)sb.frames * SHZ_NBINS * 8, &d_tr));
     uint64_t tr_pos = 0;
     for (uint32_t i = 0; i < nc; ++i) {
@@ -916,6 +1051,204 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   return SHZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The batch path: shz_peaks / shz_fingerprint_batch.  One pass = every sub-batch queued on the stream with NO host
+// read-back in between: peak counts, hash counts, output offsets and overflow flags live in the device control block
+// (xctl) and come back with ONE copy + sync at the end.  List capacities are estimates; a pass whose flags say that an
+// estimate was too small, or that fp32 staging cannot decide the input (XF_FALLBACK), is repeated with the measured
+// sizes / with fp64 staging.
+struct xparams {
+  bool f32;                    // fp32 staging + verification (default) or fp64 staging with the exact test in-kernel
+  uint32_t peaks_per_frame;    // peak list capacity per frame of a sub-batch
+  uint64_t stage_cap;          // host output: capacity of the device staging arrays (entries)
+};
+
+#define UND_CAP (1u << 20)
+
+template <int NW, int OCC>
+static void launch_pick32(shz_ctx* ctx, const p32_args& pa, uint32_t n_segs) {
+  hipLaunchKernelGGL((peak_pick32_kernel<NW, OCC>), dim3(pa.n_slabs, n_segs), dim3(64 * NW), 0, ctx->stream, pa);
+}
+static int p32_occ() {
+  static const int v = [] { const char* e = getenv("SHZ_PEAK_OCC"); const int x = e ? atoi(e) : 4; return x >= 3 && x <= 6 ? x : 4; }();
+  return v;
+}
+
+static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
+                            double amp_min, uint32_t fan, uint32_t flags, bool want_hashes, const xparams& xp,
+                            uint16_t* peak_f, uint32_t* peak_t, uint32_t* key32, uint32_t* t1, uint64_t* offs_out,
+                            uint64_t cap, xctl* hctl) {
+  const bool out_dev = (flags & SHZ_OUT_DEVICE) != 0;
+  const mask_geom mg = xp.f32 ? mg_f32(p32_nw()) : MG_F64;
+  std::vector<sub_batch> subs;
+  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, xp.f32 ? (uint64_t)P32_STRIDE * 4 : (uint64_t)DB_STRIDE * 8, subs));
+  void *p_ctl, *p_offs;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, sizeof(xctl) + 64, &p_ctl));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
+  xctl* d_ctl = (xctl*)p_ctl;
+  unsigned long long* d_offs = (unsigned long long*)p_offs;
+  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, sizeof(xctl), ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(d_offs, 0, 8, ctx->stream));
+  // where the entries go: the caller's device arrays, or staging arrays that are copied out after the final sync
+  void *o_a = want_hashes ? (void*)key32 : (void*)peak_f, *o_b = want_hashes ? (void*)t1 : (void*)peak_t;
+  uint64_t o_cap = cap;
+  if (!out_dev) {
+    o_cap = xp.stage_cap;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, o_cap * 4 + 64, &o_a));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, o_cap * 4 + 64, &o_b));
+  }
+  double p_lo, p_hi;
+  threshold_band(amp_min, &p_lo, &p_hi);
+  std::vector<std::vector<uint64_t>> keep;
+  for (const sub_batch& sb : subs) {
+    const uint32_t nc = sb.c1 - sb.c0;
+    const int16_t* d_pcm;
+    uint64_t base;
+    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
+    sub_dev sd;
+    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, mg.n_slabs, xp.f32 ? 12 / mg.nw : 3, sd, keep));
+    const uint64_t n_words = (uint64_t)sb.frames * mg.n_slabs * mg.nw;
+    if (n_words >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "too many mask words in one sub-batch");
+    const uint64_t cap_peaks64 = (uint64_t)sb.frames * xp.peaks_per_frame + 4096;
+    if (cap_peaks64 * (fan > 1 ? fan - 1 : 1) >= (1ull << 32))
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "sub-batch of %u frames may yield 2^32 hashes; lower the workspace limit", sb.frames);
+    const uint32_t cap_peaks = (uint32_t)cap_peaks64;
+    void *d_pw, *d_mask, *d_woff, *d_und, *pf, *pt, *pc, *ft;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * (xp.f32 ? P32_STRIDE * 4 : DB_STRIDE * 8), &d_pw));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MASK, n_words * 8, &d_mask));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, n_words * 4, &d_woff));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, (uint64_t)cap_peaks * 2 + 64, &pf));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, (uint64_t)cap_peaks * 4 + 64, &pt));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(nc + 1) * 4 + 64, &pc));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)sb.frames * 4 + 64, &ft));
+    const stft_args sa = make_stft_args(ctx, d_pcm, sd, nc, sb.frames, fs, d_pw);
+    if (xp.f32) {
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_UND, (uint64_t)UND_CAP * 8, &d_und));
+      hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);
+      SHZ_HIP(ctx, hipMemsetAsync(d_mask, 0, n_words * 8, ctx->stream));  // peak_pick32 writes non-zero words only
+      SHZ_TRY(launch_stft<float>(ctx, sa));
+      {
+        shz_prof_scope ps(ctx, 1);
+        p32_args pa;
+        pa.A = (const float*)d_pw;
+        pa.segs = sd.d_segs;
+        pa.n_slabs = mg.n_slabs;
+        pa.p_lo = (float)p_lo;   // fp32(P) < fp32(p_lo) => P < p_lo; fp32(P) > fp32(p_hi) => P > p_hi (monotone rounding)
+        pa.p_hi = (float)p_hi;
+        pa.mask = (uint64_t*)d_mask;
+        pa.und_list = (uint64_t*)d_und;
+        pa.ctl = d_ctl;
+        pa.und_cap = UND_CAP;
+        switch (mg.nw * 10 + p32_occ()) {
+          case 13: launch_pick32<1, 3>(ctx, pa, sd.n_segs); break;
+          case 14: launch_pick32<1, 4>(ctx, pa, sd.n_segs); break;
+          case 23: launch_pick32<2, 3>(ctx, pa, sd.n_segs); break;
+          case 33: launch_pick32<3, 3>(ctx, pa, sd.n_segs); break;
+          case 43: launch_pick32<4, 3>(ctx, pa, sd.n_segs); break;
+          case 44: launch_pick32<4, 4>(ctx, pa, sd.n_segs); break;
+          case 63: launch_pick32<6, 3>(ctx, pa, sd.n_segs); break;
+          case 73: launch_pick32<7, 3>(ctx, pa, sd.n_segs); break;
+          default: launch_pick32<2, 4>(ctx, pa, sd.n_segs); break;  // 128 VGPRs, 4 waves per SIMD: 2.12 ms vs 2.49 at 3
+        }
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+      {
+        shz_prof_scope ps(ctx, 4);
+        verify_args va;
+        va.st = sa;
+        va.A = (const float*)d_pw;
+        va.mask = (uint64_t*)d_mask;
+        va.mg = mg;
+        va.und_list = (const uint64_t*)d_und;
+        va.ctl = d_ctl;
+        va.und_cap = UND_CAP;
+        va.p_hi32 = (float)p_hi;
+        va.p_lo = p_lo;
+        va.p_hi = p_hi;
+        va.amp_min = amp_min;
+        hipLaunchKernelGGL(peak_verify_kernel, dim3((unsigned)ctx->prop.multiProcessorCount), dim3(256), 0,
+                           ctx->stream, va);
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+    } else {
+      SHZ_TRY(launch_stft<double>(ctx, sa));
+      {
+        shz_prof_scope ps(ctx, 1);
+        hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(mg.n_slabs, sd.n_segs), dim3(256), 0, ctx->stream,
+                           (const double*)d_pw, (uint32_t)DB_STRIDE, (uint32_t)SHZ_NBINS, sd.d_segs, mg.n_slabs, amp_min,
+                           p_lo, p_hi, (uint64_t*)d_mask);
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+      if (amp_min < 0.0 && n_words) {  // see peak_zero_plateau_kernel
+        hipLaunchKernelGGL(peak_zero_plateau_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (uint64_t*)d_mask, n_words, mg, (const double*)d_pw, (uint32_t)DB_STRIDE, (uint32_t)SHZ_NBINS,
+                           1.0, sd.d_foff, nc);
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+    }
+    {
+      shz_prof_scope ps(ctx, 2);
+      SHZ_TRY(shz_scan_popc64(ctx, (const uint64_t*)d_mask, (uint32_t*)d_woff, n_words, (uint64_t*)&d_ctl->sub_peaks));
+      hipLaunchKernelGGL(xctl_after_peaks_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, UND_CAP);
+      if (n_words) {
+        hipLaunchKernelGGL(frame_time_kernel, dim3((sb.frames + 255) / 256), dim3(256), 0, ctx->stream, sd.d_foff, nc,
+                           sb.frames, (uint32_t*)ft);
+        hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
+                           (uint16_t*)pf, (uint32_t*)pt, cap_peaks);
+      }
+      hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                         (const uint32_t*)d_woff, (const uint64_t*)&d_ctl->sub_peaks, sd.d_foff,
+                         (uint64_t)mg.n_slabs * mg.nw, n_words, nc, (uint32_t*)pc, cap_peaks);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+    if (!want_hashes) {
+      hipLaunchKernelGGL(xctl_offsets_kernel, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, d_ctl, false,
+                         (const uint32_t*)pc, nc, sb.c0, d_offs);
+      hipLaunchKernelGGL(peaks_out_kernel, dim3((cap_peaks + 255) / 256), dim3(256), 0, ctx->stream, d_ctl,
+                         (const uint16_t*)pf, (const uint32_t*)pt, cap_peaks, (uint16_t*)o_a, (uint32_t*)o_b, o_cap);
+      hipLaunchKernelGGL(xctl_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, false);
+      SHZ_HIP(ctx, hipGetLastError());
+      continue;
+    }
+    {
+      shz_prof_scope ps(ctx, 3);
+      void *d_cnt, *d_hoff, *d_choff;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)cap_peaks * 4 + 64, &d_cnt));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)cap_peaks * 4 + 64, &d_hoff));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)(nc + 1) * 4 + 64, &d_choff));
+      const unsigned nb = (cap_peaks + 255) / 256;
+      hipLaunchKernelGGL(pair_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t*)pt, (const uint32_t*)pc,
+                         nc, &d_ctl->sub_peaks, cap_peaks, fan, (uint32_t*)d_cnt);
+      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)d_cnt, (uint32_t*)d_hoff, cap_peaks, (uint64_t*)&d_ctl->sub_hashes));
+      hipLaunchKernelGGL(pair_write_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const uint16_t*)pf, (const uint32_t*)pt,
+                         (const uint32_t*)pc, nc, &d_ctl->sub_peaks, cap_peaks, fan, (const uint32_t*)d_hoff,
+                         (uint32_t*)o_a, (uint32_t*)o_b, (uint64_t)0, &d_ctl->hash_base, o_cap);
+      // per-clip hash offsets: hoff[pcoff[c]] (pcoff is clamped to cap_peaks; slot cap_peaks of the scan = the total)
+      hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                         (const uint32_t*)d_hoff, (const uint64_t*)&d_ctl->sub_hashes, (const uint32_t*)pc, (uint64_t)1,
+                         (uint64_t)cap_peaks, nc, (uint32_t*)d_choff, 0xFFFFFFFFu);
+      hipLaunchKernelGGL(xctl_offsets_kernel, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, d_ctl, true,
+                         (const uint32_t*)d_choff, nc, sb.c0, d_offs);
+      hipLaunchKernelGGL(xctl_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, true);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+  }
+  // the one read-back of the pass
+  SHZ_HIP(ctx, hipMemcpyAsync(hctl, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
+  if (offs_out) SHZ_HIP(ctx, shz_memcpy(ctx, offs_out, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t total = want_hashes ? hctl->hash_base : hctl->peak_base;
+  const bool clean = !(hctl->flags & (XF_FALLBACK | XF_PEAK_CAP));
+  if (clean && !out_dev && total <= cap && total <= o_cap && total) {
+    const uint64_t b_a = want_hashes ? 4 : 2;
+    SHZ_HIP(ctx, shz_memcpy(ctx, want_hashes ? (void*)key32 : (void*)peak_f, o_a, total * b_a, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, shz_memcpy(ctx, want_hashes ? (void*)t1 : (void*)peak_t, o_b, total * 4, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SHZ_OK;
+}
+
 // shared driver for shz_peaks / shz_fingerprint_batch
 static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
                               double amp_min, uint32_t fan, uint32_t flags, bool want_hashes,
@@ -925,75 +1258,73 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
                               uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count) {
   SHZ_TRY(check_common(ctx, pcm, clip_off, n_clips, fs));
   if (want_hashes && (fan < 1 || fan > 64)) SHZ_FAIL(ctx, SHZ_E_INVALID, "fan_value must be in [1,64]");
-  std::vector<sub_batch> subs;
-  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, subs));
-  const bool out_dev = (flags & SHZ_OUT_DEVICE) != 0;
-  uint64_t total = 0;  // peaks or hashes emitted so far
-  if (want_hashes ? (hash_off != nullptr) : (peak_off != nullptr)) (want_hashes ? hash_off : peak_off)[0] = 0;
-  for (const sub_batch& sb : subs) {
-    const uint32_t nc = sb.c1 - sb.c0;
-    const int16_t* d_pcm;
-    uint64_t base;
-    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
-    sub_dev sd;
-    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, sd));
-    void* d_db;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * DB_STRIDE * 8, &d_db));
-    SHZ_TRY(launch_stft(ctx, d_pcm, sd, nc, sb.frames, fs, (double*)d_db));
-    uint16_t* d_pf;
-    uint32_t *d_pt, *d_pcoff, n_peaks;
-    SHZ_TRY(run_peaks(ctx, (const double*)d_db, DB_STRIDE, SHZ_NBINS, sd, nc, sb.frames, amp_min, true, &d_pf, &d_pt,
-                      &d_pcoff, &n_peaks));
-    if (!want_hashes) {
-      std::vector<uint32_t> pco(nc + 1);
-      SHZ_HIP(ctx, shz_memcpy(ctx, pco.data(), d_pcoff, (uint64_t)(nc + 1) * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (peak_off)
-        for (uint32_t i = 0; i < nc; ++i) peak_off[sb.c0 + i + 1] = total + pco[i + 1];
-      if (total + n_peaks <= cap && n_peaks) {
-        const hipMemcpyKind kd = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        SHZ_HIP(ctx, shz_memcpy(ctx, peak_f + total, d_pf, (uint64_t)n_peaks * 2, kd));
-        SHZ_HIP(ctx, shz_memcpy(ctx, peak_t + total, d_pt, (uint64_t)n_peaks * 4, kd));
-        SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      }
-      total += n_peaks;
+  uint64_t* offs = want_hashes ? hash_off : peak_off;
+  if (offs) offs[0] = 0;
+  if (count) *count = 0;
+  if (n_clips == 0) return SHZ_OK;
+  uint64_t frames = 0;
+  for (uint32_t c = 0; c < n_clips; ++c) frames += shz_frame_count(clip_off[c + 1] - clip_off[c]);
+  static const bool force_f64 = [] { const char* e = getenv("SHZ_STAGE_F64"); return e && atoi(e) != 0; }();
+  xparams xp;
+  // fp32 staging needs the threshold to be a positive normal fp32 power well inside the range; amp_min < 0 also needs
+  // the zero-plateau rule (peak_zero_plateau_kernel), which reads the fp64 array
+  xp.f32 = !force_f64 && !ctx->stage_f64 && amp_min >= 0.0 && amp_min <= 300.0;
+  xp.peaks_per_frame = 12;                                      // 4.6 per frame on noise and music-like input
+  const uint64_t per_frame_out = want_hashes ? (uint64_t)xp.peaks_per_frame * (fan > 1 ? fan - 1 : 0) : xp.peaks_per_frame;
+  xp.stage_cap = std::min<uint64_t>(cap, frames * per_frame_out + 4096);
+  xctl h;
+  for (int attempt = 0;; ++attempt) {
+    SHZ_TRY(extract_pass(ctx, pcm, clip_off, n_clips, fs, amp_min, fan, flags, want_hashes, xp, peak_f, peak_t, key32, t1,
+                         offs, cap, &h));
+    ctx->st_und += h.und_total;
+    ctx->st_und_f64 += h.und_f64;
+    ctx->st_und_ffts += h.und_ffts;
+    const uint64_t total = want_hashes ? h.hash_base : h.peak_base;
+    bool again = false;
+    if (xp.f32 && (h.flags & XF_FALLBACK)) {  // stationary / plateau material: decide on fp64 values
+      xp.f32 = false;
+      ++ctx->st_fallbacks;
+      again = true;
+    }
+    if (h.flags & XF_PEAK_CAP) {
+      // a sub-batch had more peaks than estimated: size the lists for the densest one seen (per frame of the smallest
+      // sub-batch it could have been: all of them hold >= 64 frames or the whole call)
+      const uint64_t f_min = std::min<uint64_t>(frames, 64);
+      xp.peaks_per_frame = (uint32_t)std::min<uint64_t>(SHZ_NBINS, h.max_sub_peaks / f_min + 1);
+      if (attempt >= 1) xp.peaks_per_frame = SHZ_NBINS;  // every cell a peak: the bound
+      again = true;
+    }
+    if (!again && !(flags & SHZ_OUT_DEVICE) && total > xp.stage_cap && total <= cap) {
+      xp.stage_cap = total;  // staging estimate too small, caller's arrays are not
+      again = true;
+    }
+    if (again) {
+      if (attempt >= 4) SHZ_FAIL(ctx, SHZ_E_STATE, "extract: no stable sizing after %d passes", attempt + 1);
+      if (!(flags & SHZ_OUT_DEVICE))
+        xp.stage_cap = std::max(xp.stage_cap, std::min<uint64_t>(cap, frames * (uint64_t)xp.peaks_per_frame *
+                                                                          (want_hashes ? (fan > 1 ? fan - 1 : 0) : 1) + 4096));
       continue;
     }
-    if ((uint64_t)n_peaks * (fan > 1 ? fan - 1 : 0) >= (1ull << 32))
-      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "sub-batch yields %u peaks; lower the workspace limit so hash counts stay < 2^32", n_peaks);
-    // hashes: write straight into the caller's device arrays, or into a staging pair for host output
-    uint32_t *d_key, *d_t1;
-    uint64_t out_base, dcap;
-    if (out_dev) {
-      d_key = key32;
-      d_t1 = t1;
-      out_base = total;
-      dcap = cap;
-    } else {
-      void *pk, *pt1;
-      const uint64_t upper = (uint64_t)n_peaks * (fan > 1 ? fan - 1 : 0);
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, upper * 4 + 64, &pk));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, upper * 4 + 64, &pt1));
-      d_key = (uint32_t*)pk;
-      d_t1 = (uint32_t*)pt1;
-      out_base = 0;
-      dcap = upper;
-    }
-    uint64_t n_h = 0;
-    std::vector<uint32_t> choff;
-    SHZ_TRY(run_pairs(ctx, d_pf, d_pt, d_pcoff, nc, n_peaks, fan, d_key, d_t1, out_base, dcap, &n_h, &choff));
-    if (hash_off)
-      for (uint32_t i = 0; i < nc; ++i) hash_off[sb.c0 + i + 1] = total + choff[i + 1];
-    if (!out_dev && total + n_h <= cap && n_h) {
-      SHZ_HIP(ctx, shz_memcpy(ctx, key32 + total, d_key, n_h * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, shz_memcpy(ctx, t1 + total, d_t1, n_h * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    total += n_h;
+    if (count) *count = total;
+    if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)total,
+                              (unsigned long long)cap);
+    return SHZ_OK;
   }
-  if (count) *count = total;
-  if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)total,
-                            (unsigned long long)cap);
+}
+
+extern "C" int32_t shz_set_stage_f64(shz_ctx* ctx, int32_t enabled) {
+  if (!ctx) return SHZ_E_INVALID;
+  ctx->stage_f64 = enabled != 0;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_extract_stats(shz_ctx* ctx, uint64_t* undecided, uint64_t* decided_f64, uint64_t* frames_recomputed,
+                                     uint64_t* f64_passes) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (undecided) *undecided = ctx->st_und;
+  if (decided_f64) *decided_f64 = ctx->st_und_f64;
+  if (frames_recomputed) *frames_recomputed = ctx->st_und_ffts;
+  if (f64_passes) *f64_passes = ctx->st_fallbacks;
   return SHZ_OK;
 }
 

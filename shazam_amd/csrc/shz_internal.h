@@ -62,6 +62,9 @@ enum {
   SHZ_WS_SORT_C,
   SHZ_WS_SORT_D,
   SHZ_WS_SORT_H,
+  SHZ_WS_CTL,        // device control block of the extraction pass (xctl)
+  SHZ_WS_OFFS,       // per-clip output offsets (u64)
+  SHZ_WS_UND,        // undecided cells of fp32 peak picking
   SHZ_WS_M0, SHZ_WS_M1, SHZ_WS_M2, SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7,
   SHZ_WS_COUNT
 };
@@ -88,6 +91,10 @@ struct shz_ctx {
   std::vector<struct shz_prof_rec> prof_free;
   // match stats
   uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
+  // extraction stats: cells fp32 peak picking left undecided, of those decided on fp64 values, frames recomputed for
+  // that, passes repeated with fp64 staging
+  uint64_t st_und = 0, st_und_f64 = 0, st_und_ffts = 0, st_fallbacks = 0;
+  bool stage_f64 = false;       // shz_set_stage_f64: stage fp64 power and decide ties in peak_pick (no fp32 pass)
   // pinned bounce buffers of shz_memcpy (two halves, an event each)
   void* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
