@@ -3,25 +3,32 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): audio-seconds fingerprinted per second, 44.1 kHz mono int16.
+Metric (BASELINE.json): audio-seconds fingerprinted per second, 44.1 kHz mono int16; second half: query match
+latency against a 1M-song table (the `match_1M` extra, N = 1 only).
 Workload (BASELINE configs[1]): per GPU a batch of 1,000 synthetic 30 s clips resident in HBM,
 fingerprint-only: PCM -> STFT -> dB -> 21x21 peaks -> pair hashes (key32, t1) compacted on
-the device.  One "step" = one pass over that batch.  N > 1 (launched by torch.distributed.run)
-is weak scaling: every rank fingerprints its own 1,000 clips; `value` = all ranks' audio
-seconds / max-over-ranks wall time of the K timed steps.
+the device.  One "step" = one pass over that batch.  N > 1 is weak scaling: every rank fingerprints its own
+1,000 clips; `value` = all ranks' audio seconds / max-over-ranks wall time of the K timed steps.  Launched by
+torch.distributed.run (RANK / WORLD_SIZE in the environment) or, when --gpus N > 1 is given without that
+environment, by this script itself: N child processes, one per GPU, started before any HIP call.
 
 Beside the headline line the JSON carries
-  roofline      dominant kernel's bytes/launch over its HIP-event duration vs HBM peak
+  roofline      dominant kernel: ALGORITHMIC bytes (4,096 B PCM + 8 B per hash, per frame) per launch over
+                its HIP-event duration vs the HBM peak (`achieved`, `frac`); the bytes the kernel itself moves per
+                launch (`staged_*`), the PMC-measured traffic (`traffic`) and the whole step's figure beside it
   cpu_baseline  the reference's numpy/scipy/mlab call sequence (oracle/thirdparty_ref.py)
                 timed on this box's host cores over a bounded sample (rank 0, N = 1 only)
   db_build      fingerprints -> HBM table (with the RCCL all-gather when N > 1), untimed extra
   match         batched recognise against that table, untimed extra
+  single_query  one 5 s query at a time through recognize(): p50 / p99 latency
+  match_1M      1M x 30 s tracks in one HBM table (1.1e10 rows): per-batch latency at batch sizes 1 and 200
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,17 +40,19 @@ sys.path.insert(0, ROOT)
 FS = 44100
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured stream rates of the box
 #                        (copy ~5.0, read ~6.2, write ~4.0 TB/s) go into roofline.measured_stream_GBs
-STFT_BYTES_PER_FRAME = 4096 + 2049 * 8   # new PCM read + dB row written (staged kernel I/O)
-COMPULSORY_BYTES_PER_FRAME = 4096 + 147  # PCM in + ~18.4 hashes x 8 B out
+PCM_BYTES_PER_FRAME = 4096               # 2,048 new int16 samples per frame
+# bytes each kernel itself moves per frame with fp32 staging (the default; fp64 staging doubles the 2049-bin rows)
+STAGED_BYTES_PER_FRAME = {"stft_psd": 4096 + 2049 * 4, "peak_pick": 2049 * 4 + 288}
+PMC_PROFILE = "r02_pmc_traffic.json"
+PMC_KERNELS = {"stft_psd": "stft_psd_kernel<float>", "peak_pick": "peak_pick32_kernel<2, 4>"}
 
 
 def pmc_traffic(kernel, frames_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), scaled to this
     run's frames per launch; None when no profile of that kernel is committed."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))
-        k = {"stft_psd": "stft_psd_kernel", "peak_pick": "peak_pick_kernel<true>"}[kernel]
-        return prof["kernels"][k]["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000)
+        prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+        return prof["kernels"][PMC_KERNELS[kernel]]["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000)
     except Exception:
         return None
 
@@ -57,27 +66,58 @@ def cpu_worker(args):
     return time.perf_counter() - t0, len(h)
 
 
+def _cpu_budget():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return aff, quota
+
+
 def cpu_baseline(n_samples, budget_s=15.0):
-    """Reference call sequence (mlab.specgram + scipy.ndimage + hashlib) over a Pool of all
-    host cores, like __init__.py:335-357.  Bounded sample: cores x k clips."""
+    """Reference call sequence (mlab.specgram + scipy.ndimage + hashlib) over a Pool of the host cores this process
+    may use, like __init__.py:335-357.  Bounded sample: pool x k clips.  Library threads are pinned to one per
+    worker so that `cores` workers mean `cores` busy threads."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[v] = "1"   # inherited by the forked workers; numpy's FFT and scipy.ndimage are single-threaded anyway
+    aff, quota = _cpu_budget()
+    pool_n = max(1, min(aff, int(quota) if quota else aff))
     t1 = cpu_worker((1234, 0, n_samples))[0]          # single-core time per clip (also warms imports)
     per_proc = max(1, int(budget_s / max(t1 * 2.5, 1e-3)))
     per_proc = min(per_proc, 4)
-    clips = cores * per_proc
+    clips = pool_n * per_proc
     ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        pool.map(cpu_worker, [(1234, c, n_samples // 8) for c in range(cores)])  # warm-up
+    with ctx.Pool(pool_n) as pool:
+        pool.map(cpu_worker, [(1234, c, n_samples // 8) for c in range(pool_n)])  # warm-up
         t0 = time.perf_counter()
         res = pool.map(cpu_worker, [(1234, c, n_samples) for c in range(clips)], chunksize=1)
         wall = time.perf_counter() - t0
     audio_s = clips * n_samples / FS
-    return {"value": audio_s / wall, "unit": "audio-s/s", "cores": cores, "kind": "port",
+    busy = float(sum(r[0] for r in res))   # CPU-seconds the workers spent inside fingerprint()
+    return {"value": audio_s / wall, "unit": "audio-s/s", "cores": pool_n, "kind": "port",
+            "affinity_cpus": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+            "effective_parallelism": busy / wall,
             "single_core_value": (n_samples / FS) / t1,
             "sample": f"{clips} synthetic {n_samples / FS:.0f} s clips (same generator/seed as the GPU run) through "
                       f"oracle/thirdparty_ref.py (mlab.specgram + scipy.ndimage + hashlib, the reference's call sites) "
-                      f"on a multiprocessing.Pool({cores}); synth time excluded; wall {wall:.1f} s",
+                      f"on a multiprocessing.Pool({pool_n}) = min(affinity {aff}, cgroup quota {quota}), one library "
+                      f"thread per worker; synth time excluded; wall {wall:.1f} s; effective_parallelism = sum of the "
+                      f"workers' in-call seconds / wall",
             "hashes_per_clip": float(np.mean([r[1] for r in res]))}
 
 
@@ -93,7 +133,7 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
         bw = {m: ctx.membw(i, 2 << 30, 5) for i, m in enumerate(("copy", "read", "write"))}
         rf = out["roofline"]
         rf["measured_stream_GBs"] = bw
-        rf["frac_of_measured_copy"] = rf["achieved"] / bw["copy"] if bw["copy"] > 0 else None
+        rf["staged_frac_of_measured_copy"] = rf["staged_achieved"] / bw["copy"] if bw["copy"] > 0 else None
     except Exception as e:  # noqa: BLE001
         out["roofline"]["measured_stream_error"] = repr(e)
 
@@ -157,6 +197,11 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
     t_host = time.perf_counter() - t0
     out["pcie_inclusive"] = {"clips": nh, "audio_s_per_s": nh * n_samples / FS / t_host,
                              "note": "host int16 PCM in, host (key32,t1) out, pageable memory; never the headline value"}
+    # One query at a time through the reference-shaped entry point (host PCM in, result dicts out): serving latency
+    try:
+        out["single_query"] = single_query_latency(ctx, tbl, rank, nc, n_samples)
+    except Exception as e:  # noqa: BLE001
+        out["single_query"] = {"error": repr(e)}
     tbl.close()
     if comm:
         comm.close()
@@ -195,6 +240,88 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
         ctx2.close()
 
 
+def single_query_latency(ctx, tbl, rank, nc, n_samples, n_iter=60):
+    """p50 / p99 of ONE 5 s query: fingerprint (host int16 in) + match (top-2) per call, against the step's table."""
+    from oracle import synth   # input generator only
+    q = synth.synth_clip(1234, rank * nc + 7, n_samples, 0, 8000)[13 * 2048 + 77:13 * 2048 + 77 + 5 * FS]
+    qoff = np.array([0, len(q)], np.uint64)
+    lat = {"fingerprint": [], "match": [], "total": []}
+    top = None
+    for i in range(n_iter + 5):
+        t0 = time.perf_counter()
+        k, t1, ho, _ = ctx.fingerprint_batch(q, qoff)
+        t1_ = time.perf_counter()
+        res = tbl.match(k, t1, ho, 2)
+        t2 = time.perf_counter()
+        if i >= 5:
+            lat["fingerprint"].append(t1_ - t0)
+            lat["match"].append(t2 - t1_)
+            lat["total"].append(t2 - t0)
+        top = (int(res["sid"][0, 0]), int(res["delta"][0, 0]))
+    o = {"queries": n_iter, "query_seconds": 5.0, "top1": {"song_id": top[0], "offset": top[1]},
+         "expected": {"song_id": rank * nc + 8, "offset": 13},
+         "note": "host PCM in, host results out, one query per call; crop at sample 13*2048+77 of track 7"}
+    for k_, v in lat.items():
+        v = np.array(v) * 1e3
+        o[f"{k_}_p50_ms"] = float(np.median(v))
+        o[f"{k_}_p99_ms"] = float(np.percentile(v, 99))
+    return o
+
+
+def match_1m(ctx, songs, info):
+    """Second half of BASELINE's metric: query match latency against a 1M-song table (1M x 30 s tracks, 1.1e10 rows,
+    ~136 GB in one GPU's HBM).  10 s noisy crops (SNR 10 dB, the reference's mixing rule), true wall time per match call
+    at batch sizes 1 and 200 (recognizer.py:273-286 `query_time` is this stage in the reference: p50 0.816 s at 13 M rows)."""
+    import bench_db
+    need = songs * 11300 * 12 * 1.35   # rows x 12 B x (sort scratch + headroom)
+    if info["hbm_bytes"] < need:
+        return {"skipped": f"needs ~{need / 1e9:.0f} GB of HBM"}
+    t0 = time.perf_counter()
+    tbl, build, bufs = bench_db.build_table(ctx, songs, 30.0, 1000, 4000, 1500, finalize_every=100000)
+    n_samples = 30 * FS
+    qn = 10 * FS
+    o = {"songs": songs, "rows": build["rows"], "build_seconds": build["seconds_total"],
+         "build": {k: build[k] for k in ("fingerprint_s", "insert_s", "finalize_s", "songs_per_s")},
+         "query_seconds": 10.0, "snr_db": 10.0}
+    for bs, nq in ((1, 60), (200, 2000)):
+        bench_db.run_queries(ctx, tbl, songs, n_samples, bs * 2, qn, 10.0, bs, 2, seed=5)   # warm the workspace
+        r = bench_db.run_queries(ctx, tbl, songs, n_samples, nq, qn, 10.0, bs, 2, seed=99 + bs)
+        alg = (8 * r["rows_scanned"] + 16 * r["distinct_keys"]) / r["t_match"] / 1e9
+        o[f"batch{bs}"] = {"batches": int(len(r["batch_ms"])), "batch_ms_p50": float(np.percentile(r["batch_ms"], 50)),
+                           "batch_ms_p99": float(np.percentile(r["batch_ms"], 99)),
+                           "ms_per_query_p50": float(np.percentile(r["batch_ms"] / r["sizes"], 50)),
+                           "qps": nq / r["t_match"], "top1_accuracy": r["correct"] / nq,
+                           "rows_scanned_per_query": r["rows_scanned"] / nq, "pairs_per_query": r["pairs"] / nq,
+                           "hashes_per_query": r["hashes"] / nq, "alg_GBs": alg, "alg_frac_of_hbm_peak": alg / HBM_PEAK_GBS,
+                           "query_fingerprint_ms": r["query_fingerprint_s"] / nq * 1e3}
+    o["p50_ms"] = o["batch1"]["batch_ms_p50"]
+    o["p99_ms"] = o["batch1"]["batch_ms_p99"]
+    o["seconds_total"] = time.perf_counter() - t0
+    tbl.close()
+    for b in bufs[:2]:
+        b.free()
+    return o
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) before this process
+    touches HIP, relay their output, exit with the worst return code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        p_.wait()
+        rc = rc or p_.returncode
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,13 +332,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--queries", type=int, default=2000)
+    ap.add_argument("--match-songs", type=int, default=1000000, help="tracks of the match_1M extra (0 = skip)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)   # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with "
+                         f"torch.distributed.run --nproc-per-node {a.gpus} or without a launcher")
     dist = None
     if world > 1:
         # torch.distributed is rendezvous plumbing only (barrier, max, id broadcast) on gloo/CPU;
@@ -266,20 +397,31 @@ def main():
     value = world * audio_s_per_step * a.steps / elapsed
     frames_per_step = nc * frames_per_clip
 
-    # roofline of the dominant kernel, from the HIP events recorded inside the timed region
-    dom = max(kms, key=lambda k: kms[k][0])
+    # roofline of the dominant kernel, from the HIP events recorded inside the timed region.
+    # `achieved` / `frac` follow SURVEY 8(d): the implementation-independent bytes of the path (PCM in, hashes out) that
+    # one launch of the kernel serves, over the kernel's own average duration; the bytes the kernel actually moves
+    # (fp32 power rows staged through HBM) are the staged_* keys, the PMC-measured traffic is `traffic`.
+    dom = max((k for k in kms if k in STAGED_BYTES_PER_FRAME), key=lambda k: kms[k][0])
     dom_ms, dom_launches = kms[dom]
     frames_per_launch = frames_per_step * a.steps / max(dom_launches, 1)
     avg_ms = dom_ms / max(dom_launches, 1)
-    bytes_per_frame = {"stft_psd": STFT_BYTES_PER_FRAME, "peak_pick": 2049 * 8 + 288}.get(dom, STFT_BYTES_PER_FRAME)
-    achieved = frames_per_launch * bytes_per_frame / (avg_ms * 1e-3) / 1e9
+    alg_bytes_per_frame = PCM_BYTES_PER_FRAME + 8.0 * n_hashes / frames_per_step
+    achieved = frames_per_launch * alg_bytes_per_frame / (avg_ms * 1e-3) / 1e9
+    staged = frames_per_launch * STAGED_BYTES_PER_FRAME[dom] / (avg_ms * 1e-3) / 1e9
+    step_alg = frames_per_step * alg_bytes_per_frame / (elapsed / a.steps) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch), "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01g_pmc_traffic.json)",
-                "accounting": f"kernel I/O bytes: {bytes_per_frame} B/frame x {frames_per_launch:.0f} frames/launch / "
-                              f"{avg_ms:.3f} ms avg launch (HIP events, {dom_launches} launches in the timed region)",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch),
+                "traffic_unit": f"GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{PMC_PROFILE})",
+                "accounting": f"algorithmic bytes (SURVEY 8d): {alg_bytes_per_frame:.0f} B/frame (4096 B PCM + 8 B x "
+                              f"{n_hashes / frames_per_step:.1f} hashes) x {frames_per_launch:.0f} frames/launch / "
+                              f"{avg_ms:.3f} ms avg launch of {dom} (HIP events, {dom_launches} launches in the timed region)",
+                "staged_achieved": staged, "staged_frac": staged / HBM_PEAK_GBS,
+                "staged_accounting": f"bytes the kernel moves: {STAGED_BYTES_PER_FRAME[dom]} B/frame (PCM in + fp32 power row out)",
                 "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kms.items()},
-                "compulsory_achieved_GBs": frames_per_step * COMPULSORY_BYTES_PER_FRAME / (elapsed / a.steps) / 1e9,
-                "compulsory_frac": frames_per_step * COMPULSORY_BYTES_PER_FRAME / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}
+                "step_achieved": step_alg, "step_frac": step_alg / HBM_PEAK_GBS,
+                "host_overhead_ms_per_step": elapsed / a.steps * 1e3 - sum(v[0] for v in kms.values()) / a.steps,
+                "note": "the path is VALU/LDS-bound, not HBM-bound (SURVEY 8d: 30 flop/B fused): frac is small by "
+                        "construction; staged_frac is the kernel's own I/O rate"}
 
     out = {"metric": "audio_seconds_fingerprinted_per_second", "value": value, "unit": "audio-s/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
@@ -300,23 +442,32 @@ def main():
         if rank == 0:
             print(json.dumps(out), flush=True)
 
-    # ---- extras (outside the timed region).  A watchdog prints the headline line and exits if the
-    # extras (RCCL init / all-gather on an unknown node) hang, so the measured value is never lost.
+    # ---- extras (outside the timed region).  A watchdog prints the headline line if the extras (RCCL init /
+    # all-gather on an unknown node) hang, so the measured value is never lost -- and exits NON-ZERO: a hang is a failure.
     if not a.no_extras:
         import threading
 
         def on_timeout():   # runs in its own thread: a hung RCCL call inside ctypes cannot block it
-            out["extras_error"] = "extras timed out after 240 s"
+            out["extras_error"] = "extras timed out after 420 s"
             emit()
-            os._exit(0)
+            os._exit(3)
 
-        dog = threading.Timer(240.0, on_timeout)
+        dog = threading.Timer(420.0, on_timeout)
         dog.daemon = True
         dog.start()
+        out["extract_stats"] = ctx.extract_stats()
         try:
             extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elapsed, pcm, out)
         except Exception as e:  # noqa: BLE001 -- extras must never cost the headline number
             out["extras_error"] = repr(e)
+        if world == 1 and a.match_songs > 0:
+            try:
+                for b_ in (kbuf, tbuf, pcm):
+                    b_.free()
+                ctx.release_workspace()
+                out["match_1M"] = match_1m(ctx, a.match_songs, info)
+            except Exception as e:  # noqa: BLE001
+                out["match_1M"] = {"error": repr(e)}
         dog.cancel()
     emit()
     if dist:

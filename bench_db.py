@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench_db.py -- database build + batched noisy-query match on ONE MI355X (BASELINE configs 3/4,
 scaled to what a replicated < 2^32-row table holds).  Not the driver's headline bench (that is
-bench.py); this is the second half of the metric: "query match ms vs an N-song DB".
+bench.py); this is the second half of the metric: "query match ms vs an N-song DB".  bench.py imports
+build_table / make_queries / run_queries from here for its `match_1M` extra.
 
     python bench_db.py --songs 100000 --seconds 30 --queries 10000 --snr 0
 
 Tracks: synthetic tonal+noise clips generated on the device (oracle twin: oracle/synth.py).
 Queries: 5 s crops at arbitrary (not hop-aligned) sample offsets, mixed on the device with an
 independent noise stream at the requested SNR using the reference's rule
-(recognizer_test.py:426-435), fingerprinted and matched in batches.  Prints one JSON line.
+(recognizer_test.py:426-435; ADD_NOISE / SNR at :39-40), fingerprinted and matched in batches.
+Prints one JSON line.
 """
 from __future__ import annotations
 
@@ -23,6 +25,113 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FS = 44100
+SEED_TRACKS, SEED_NOISE = 4321, 777
+
+
+def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1500, finalize_every=0, shards=1,
+                progress=None):
+    """Synthesise `songs` tracks on the device, fingerprint them in chunks and build one HBM table.
+    Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
+    from shazam_amd import _ffi, Table
+    n_samples = int(round(seconds * FS))
+    frames = int(_ffi.lib().shz_frame_count(n_samples))
+    if shards > 1:
+        from shazam_amd.shard import ShardedTable
+        tbl = ShardedTable(ctx, nshards=shards)
+    else:
+        tbl = Table(ctx)
+    cap = chunk * frames * 24 + 1024
+    kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
+    pcm = ctx.alloc(chunk * n_samples * 2)
+    t_fp = t_ins = t_fin = 0.0
+    n_rows_in = 0
+    t_build0 = time.perf_counter()
+    for c0 in range(0, songs, chunk):
+        nc = min(chunk, songs - c0)
+        ctx.synth_pcm(SEED_TRACKS, c0, nc, n_samples, tone_amp, noise_amp, out=pcm)
+        off = np.arange(nc + 1, dtype=np.uint64) * n_samples
+        ctx.sync()
+        t0 = time.perf_counter()
+        _, _, ho, cnt = ctx.fingerprint_batch(pcm, off, fs=FS, pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
+        ctx.sync()
+        t_fp += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
+        t_ins += time.perf_counter() - t0
+        n_rows_in += cnt
+        if finalize_every and (c0 + nc) % finalize_every == 0 and c0 + nc < songs:
+            t0 = time.perf_counter()
+            tbl.finalize()        # bounds staged rows + sort scratch; a full active segment is frozen
+            ctx.sync()
+            t_fin += time.perf_counter() - t0
+            if progress:
+                progress(c0 + nc)
+    t0 = time.perf_counter()
+    tbl.finalize()
+    ctx.sync()
+    t_fin += time.perf_counter() - t0
+    t_build = time.perf_counter() - t_build0
+    rows, _ = tbl.rows()
+    pcm.free()
+    stats = {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
+             "rows_inserted": int(n_rows_in), "rows": int(rows), "songs_per_s": songs / t_build,
+             "audio_s_per_s": songs * seconds / t_build}
+    return tbl, stats, (kbuf, tbuf, cap)
+
+
+def make_queries(ctx, tids, starts, qn, snr, tone_amp=4000, noise_amp=1500, noise_clip0=0):
+    """Device PCM of len(tids) queries: crop [start, start+qn) of track tid, mixed with an independent noise stream at
+    `snr` dB by the reference's rule (snr >= 200: clean).  Returns (DevBuf, buffers to free)."""
+    from shazam_amd import _ffi
+    nb = len(tids)
+    sig, noi = ctx.alloc(nb * qn * 2), ctx.alloc(nb * qn * 2)
+    for i in range(nb):
+        ctx.check(_ffi.lib().shz_synth_pcm(ctx.h, SEED_TRACKS, int(tids[i]), 1, qn, tone_amp, noise_amp, int(starts[i]),
+                                           _ffi.vp(sig.ptr + i * qn * 2)))
+    ctx.synth_pcm(SEED_NOISE, noise_clip0, nb, qn, 0, 8000, out=noi)
+    q = ctx.mix_snr(sig, noi, nb, qn, snr) if snr < 200 else sig
+    return q, [b for b in (sig, noi, q) if b is not None]
+
+
+def run_queries(ctx, tbl, songs, n_samples, nq, qn, snr, match_batch, topn=2, tone_amp=4000, noise_amp=1500, seed=99,
+                before_batch=None):
+    """nq queries in batches of match_batch: fingerprint + match, wall time of the match call per batch.
+    Returns a dict with per-batch milliseconds (whole batch), accuracy and the rows/pairs the match touched."""
+    rng = np.random.default_rng(seed)
+    tids = rng.integers(0, songs, nq)
+    starts = rng.integers(0, n_samples - qn, nq)
+    batch_ms, sizes, correct, tot_pairs, tot_rows, tot_hash, tot_keys = [], [], 0, 0, 0, 0, 0
+    t_qfp = 0.0
+    for b0 in range(0, nq, match_batch):
+        nb = min(match_batch, nq - b0)
+        if before_batch:
+            before_batch()
+        q, bufs = make_queries(ctx, tids[b0:b0 + nb], starts[b0:b0 + nb], qn, snr, tone_amp, noise_amp, b0)
+        qoff = np.arange(nb + 1, dtype=np.uint64) * qn
+        ctx.sync()
+        t0 = time.perf_counter()
+        k, t1, ho, _ = ctx.fingerprint_batch(q, qoff, fs=FS, pcm_device=True)
+        t_qfp += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = tbl.match(k, t1, ho, topn)
+        dt = time.perf_counter() - t0
+        batch_ms.append(dt * 1e3)
+        sizes.append(nb)
+        st = tbl.match_stats()
+        tot_pairs += st["pairs"]
+        tot_rows += st["rows_scanned"]
+        tot_keys += st["distinct_keys"]
+        tot_hash += int(res["nhash"].sum())
+        correct += int(np.sum((res["nres"] > 0) & (res["sid"][:, 0] == 1 + tids[b0:b0 + nb])))
+        seen = set()
+        for b in bufs:
+            if id(b) not in seen:
+                seen.add(id(b))
+                b.free()
+    batch_ms, sizes = np.array(batch_ms), np.array(sizes)
+    t_match = float(batch_ms.sum() / 1e3)
+    return {"batch_ms": batch_ms, "sizes": sizes, "t_match": t_match, "correct": correct, "pairs": tot_pairs,
+            "rows_scanned": tot_rows, "distinct_keys": tot_keys, "hashes": tot_hash, "query_fingerprint_s": t_qfp}
 
 
 def main():
@@ -44,115 +153,52 @@ def main():
                     "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
     a = ap.parse_args()
 
-    from shazam_amd import _ffi, Table
+    from shazam_amd import _ffi
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     n_samples = int(round(a.seconds * FS))
-    frames = int(_ffi.lib().shz_frame_count(n_samples))
-    if a.shards > 1:
-        from shazam_amd.shard import ShardedTable
-        tbl = ShardedTable(ctx, nshards=a.shards)
-    else:
-        tbl = Table(ctx)
-    cap = a.chunk * frames * 24 + 1024
-    kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
-    pcm = ctx.alloc(a.chunk * n_samples * 2)
-    t_fp = t_ins = t_fin = 0.0
-    n_rows_in = 0
-    t_build0 = time.perf_counter()
-    for c0 in range(0, a.songs, a.chunk):
-        nc = min(a.chunk, a.songs - c0)
-        ctx.synth_pcm(4321, c0, nc, n_samples, a.tone_amp, a.noise_amp, out=pcm)
-        off = np.arange(nc + 1, dtype=np.uint64) * n_samples
-        ctx.sync()
-        t0 = time.perf_counter()
-        _, _, ho, cnt = ctx.fingerprint_batch(pcm, off, fs=FS, pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
-        ctx.sync()
-        t_fp += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
-        t_ins += time.perf_counter() - t0
-        n_rows_in += cnt
-        if a.finalize_every and (c0 + nc) % a.finalize_every == 0 and c0 + nc < a.songs:
-            t0 = time.perf_counter()
-            tbl.finalize()        # bounds staged rows + sort scratch; a full active segment is frozen
-            ctx.sync()
-            t_fin += time.perf_counter() - t0
-    t0 = time.perf_counter()
-    tbl.finalize()
-    ctx.sync()
-    t_fin += time.perf_counter() - t0
-    t_build = time.perf_counter() - t_build0
-    rows, _ = tbl.rows()
-    pcm.free()
+    tbl, build, (kbuf, tbuf, cap) = build_table(ctx, a.songs, a.seconds, a.chunk, a.tone_amp, a.noise_amp,
+                                                a.finalize_every, a.shards)
+    rows = build["rows"]
 
-    # queries
     qn = int(round(a.query_seconds * FS))
-    rng = np.random.default_rng(99)
     nq = a.queries
-    tids = rng.integers(0, a.songs, nq)
-    starts = rng.integers(0, n_samples - qn, nq)
-    lat, correct, tot_pairs, tot_rows, tot_hash = [], 0, 0, 0, 0
-    t_qfp = 0.0
     mixed = {"songs": 0, "seconds": 0.0, "finalize_s": 0.0, "batches": 0}
     n_mix = min(a.mixed_ingest, a.chunk)
     mix_pcm = ctx.alloc(n_mix * n_samples * 2) if n_mix else None
-    t_stream0 = time.perf_counter()
-    for b0 in range(0, nq, a.match_batch):
-        nb = min(a.match_batch, nq - b0)
-        if n_mix:   # new songs arrive between the query batches; their ids continue after the base corpus
-            c0 = a.songs + mixed["songs"]
-            ctx.synth_pcm(4321, c0, n_mix, n_samples, a.tone_amp, a.noise_amp, out=mix_pcm)
-            ctx.sync()
-            t0 = time.perf_counter()
-            _, _, ho_m, _ = ctx.fingerprint_batch(mix_pcm, np.arange(n_mix + 1, dtype=np.uint64) * n_samples, fs=FS,
-                                                  pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
-            tbl.insert_clips(kbuf, tbuf, ho_m, sid0=1 + c0, device=True)
-            t1_ = time.perf_counter()
-            tbl.finalize()
-            ctx.sync()
-            mixed["finalize_s"] += time.perf_counter() - t1_
-            mixed["seconds"] += time.perf_counter() - t0
-            mixed["songs"] += n_mix
-            mixed["batches"] += 1
-        sig, noi = ctx.alloc(nb * qn * 2), ctx.alloc(nb * qn * 2)
-        for i in range(nb):
-            ctx.check(_ffi.lib().shz_synth_pcm(ctx.h, 4321, int(tids[b0 + i]), 1, qn, a.tone_amp, a.noise_amp,
-                                               int(starts[b0 + i]), _ffi.vp(sig.ptr + i * qn * 2)))
-        ctx.synth_pcm(777, b0, nb, qn, 0, 8000, out=noi)
-        q = ctx.mix_snr(sig, noi, nb, qn, a.snr) if a.snr < 200 else sig
-        qoff = np.arange(nb + 1, dtype=np.uint64) * qn
+
+    def ingest_batch():   # new songs arrive between the query batches; their ids continue after the base corpus
+        c0 = a.songs + mixed["songs"]
+        ctx.synth_pcm(SEED_TRACKS, c0, n_mix, n_samples, a.tone_amp, a.noise_amp, out=mix_pcm)
         ctx.sync()
         t0 = time.perf_counter()
-        k, t1, ho, _ = ctx.fingerprint_batch(q, qoff, fs=FS, pcm_device=True)
-        t_qfp += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        res = tbl.match(k, t1, ho, a.topn)
-        dt = time.perf_counter() - t0
-        lat.append(dt / nb * 1e3)
-        st = tbl.match_stats()
-        tot_pairs += st["pairs"]
-        tot_rows += st["rows_scanned"]
-        tot_hash += int(res["nhash"].sum())
-        correct += int(np.sum((res["nres"] > 0) & (res["sid"][:, 0] == 1 + tids[b0:b0 + nb])))
-        for b in (sig, noi):
-            b.free()
-        if q is not sig:
-            q.free()
-    lat = np.array(lat)
-    t_match = float((lat * np.minimum(a.match_batch, nq - np.arange(0, nq, a.match_batch))).sum() / 1e3)
+        _, _, ho_m, _ = ctx.fingerprint_batch(mix_pcm, np.arange(n_mix + 1, dtype=np.uint64) * n_samples, fs=FS,
+                                              pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
+        tbl.insert_clips(kbuf, tbuf, ho_m, sid0=1 + c0, device=True)
+        t1_ = time.perf_counter()
+        tbl.finalize()
+        ctx.sync()
+        mixed["finalize_s"] += time.perf_counter() - t1_
+        mixed["seconds"] += time.perf_counter() - t0
+        mixed["songs"] += n_mix
+        mixed["batches"] += 1
+
+    t_stream0 = time.perf_counter()
+    r = run_queries(ctx, tbl, a.songs, n_samples, nq, qn, a.snr, a.match_batch, a.topn, a.tone_amp, a.noise_amp,
+                    before_batch=ingest_batch if n_mix else None)
+    lat = r["batch_ms"] / r["sizes"]
+    t_match = r["t_match"]
     out = {"metric": "query_match_ms_per_query_batched", "value": float(np.median(lat)), "unit": "ms/query",
            "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "qps": nq / t_match,
+           "batch_ms_p50": float(np.percentile(r["batch_ms"], 50)), "batch_ms_p99": float(np.percentile(r["batch_ms"], 99)),
            "ms_per_query_by_batch": [round(float(x), 5) for x in lat[:64]],
            "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
            "config": {"workload": f"{a.songs} x {a.seconds:.0f} s tonal+noise tracks in one HBM table; {nq} x "
                                   f"{a.query_seconds:.0f} s queries at arbitrary offsets, SNR {a.snr} dB, batches of {a.match_batch}",
                       "songs": a.songs, "rows": int(rows), "queries": nq, "snr_db": a.snr, "shards": a.shards},
-           "top1_accuracy": correct / nq, "hashes_per_query": tot_hash / nq, "pairs_per_query": tot_pairs / nq,
-           "rows_scanned_per_query": tot_rows / nq, "query_fingerprint_ms": t_qfp / nq * 1e3,
-           "match_alg_GBs": (8 * tot_rows) / t_match / 1e9,
-           "build": {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
-                     "rows_inserted": int(n_rows_in), "songs_per_s": a.songs / t_build,
-                     "audio_s_per_s": a.songs * a.seconds / t_build}}
+           "top1_accuracy": r["correct"] / nq, "hashes_per_query": r["hashes"] / nq, "pairs_per_query": r["pairs"] / nq,
+           "rows_scanned_per_query": r["rows_scanned"] / nq, "query_fingerprint_ms": r["query_fingerprint_s"] / nq * 1e3,
+           "match_alg_GBs": (8 * r["rows_scanned"] + 16 * r["distinct_keys"]) / t_match / 1e9,
+           "build": build, "extract_stats": ctx.extract_stats()}
     if n_mix:
         t_stream = time.perf_counter() - t_stream0   # includes query synthesis / mixing on the device
         out["mixed"] = {"ingest_batch_songs": n_mix, "batches": mixed["batches"], "songs_ingested": mixed["songs"],

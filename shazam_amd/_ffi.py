@@ -233,7 +233,7 @@ class Context:
         self.check(lib().shz_set_profiling(self.h, 1 if on else 0))
 
     def kernel_ms(self):
-        names = ["stft_psd", "peak_pick", "peak_expand", "pair_hash"]
+        names = ["stft_psd", "peak_pick", "peak_expand", "pair_hash", "peak_verify"]
         out = {}
         for i, n in enumerate(names):
             ms, k = C.c_float(), C.c_uint32()

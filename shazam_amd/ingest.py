@@ -80,33 +80,33 @@ class ShardedBuilder:
 # (__init__.py:248-268, 286-393, 407-415), batched for the GPU.  mp3 decoding stays external
 # (pydub/ffmpeg are not part of the hot path); WAV goes through the stdlib.
 # ---------------------------------------------------------------------------------------------
-import fnmatch
-import os
+import hashlib
 import wave
-from hashlib import sha1
+from pathlib import Path
 
 
-def unique_hash(file_path: str, block_size: int = 2 ** 20) -> str:
-    """SHA-1 of the file bytes, upper-case hex (__init__.py:305-323)."""
-    s = sha1()
-    with open(file_path, "rb") as f:
-        while True:
-            buf = f.read(block_size)
-            if not buf:
-                break
-            s.update(buf)
-    return s.hexdigest().upper()
+def unique_hash(file_path) -> str:
+    """Identity of a file for the skip-if-already-ingested rule: SHA-1 of its bytes as upper-case hex, the form the
+    songs table stores (__init__.py:305-323 defines the value; mysql_database.py:32-44 the column)."""
+    h = hashlib.sha1()
+    view = memoryview(bytearray(1 << 20))
+    with open(file_path, "rb", buffering=0) as f:
+        while n := f.readinto(view):
+            h.update(view[:n])
+    return h.hexdigest().upper()
 
 
-def find_files(path: str, extensions):
-    """(path, extension) of every file under ``path`` with one of the extensions (__init__.py:286-303)."""
-    extensions = [e.replace(".", "") for e in extensions]
-    results = []
-    for dirpath, _dirnames, files in os.walk(path):
-        for extension in extensions:
-            for f in fnmatch.filter(files, f"*.{extension}"):
-                results.append((os.path.join(dirpath, f), extension))
-    return results
+def find_files(path, extensions):
+    """[(file path, extension without dot)] for every file below ``path`` whose name ends in one of ``extensions``
+    (given with or without the dot).  Same pairs as the reference's walk (__init__.py:286-303), in sorted order so
+    that song ids do not depend on the directory's on-disk order."""
+    wanted = {e.lstrip(".") for e in extensions}
+    found = []
+    for f in sorted(Path(path).rglob("*")):
+        ext = f.suffix.lstrip(".")
+        if ext in wanted and f.is_file():
+            found.append((str(f), ext))
+    return found
 
 
 def read(file_name: str, limit: int = None):
@@ -170,7 +170,7 @@ def fingerprint_directory(path: str, extensions, db, songhashes_set=None, limit:
                 lo, hi = int(ho[pos]), int(ho[pos + nch])
                 pos += nch
                 pairs = np.unique((k[lo:hi].astype(np.uint64) << np.uint64(32)) | t1[lo:hi].astype(np.uint64))
-                song_name = os.path.splitext(os.path.basename(fn))[0]
+                song_name = Path(fn).stem
                 sid = db.insert_song(song_name, file_hash, len(pairs))
                 db.insert_keys(sid, (pairs >> np.uint64(32)).astype(np.uint32), (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32))
                 db.set_song_fingerprinted(sid)
