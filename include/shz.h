@@ -185,9 +185,15 @@ int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, const uint32
 int32_t shz_table_finalize(shz_table* t);
 /* A table is a list of sorted segments (each one radix sort, < 2^32 rows) that every probe visits; rows
  * beyond `rows` per segment open a new one at finalize.  Default 2^31; smaller values only for tests.
- * Duplicates are removed inside a segment (the caller must not insert the same song twice across
- * finalize calls that land in different segments). */
+ * UNIQUE(song_id, offset, hash) + INSERT IGNORE (mysql_database.py:54-55, 62-68) hold across segments: staged rows
+ * that already sit in a frozen segment are dropped at finalize, duplicates inside the batch by the sort. */
 int32_t shz_table_set_segment_rows(shz_table* t, uint64_t rows);
+/* ON DELETE CASCADE of fingerprints when songs are deleted (mysql_database.py:57-58; DELETE_UNFINGERPRINTED :132-134,
+ * the reference's crash recovery at __init__.py:424): every row of the listed song ids leaves the table (all segments
+ * and the staged rows), the order of the rest is kept.  sids: host array. */
+int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, uint64_t n_sids, uint64_t* rows_deleted);
+/* DROP TABLE fingerprints: no rows, no segments; allocations of the active segment are kept for the rows to come. */
+int32_t shz_table_clear(shz_table* t);
 int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged);
 /* sorted rows to host (dump / parity): arrays of cap rows */
 int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap, uint64_t* count);

@@ -60,6 +60,8 @@ SIGNATURES = {
     "shz_table_finalize": (C.c_int32, [vp]),
     "shz_table_set_segment_rows": (C.c_int32, [vp, C.c_uint64]),
     "shz_table_rows": (C.c_int32, [vp, u64p, u64p]),
+    "shz_table_delete_songs": (C.c_int32, [vp, vp, C.c_uint64, u64p]),
+    "shz_table_clear": (C.c_int32, [vp]),
     "shz_table_export": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, u64p]),
     "shz_table_lookup": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]),
     "shz_table_song_rows": (C.c_int32, [vp, C.c_uint32, u64p]),
@@ -430,6 +432,16 @@ class Table:
 
     def finalize(self):
         self.ctx.check(lib().shz_table_finalize(self.h))
+
+    def delete_songs(self, sids) -> int:
+        """Remove every row of the listed song ids (ON DELETE CASCADE, mysql_database.py:57-58); returns rows removed."""
+        a = np.ascontiguousarray(sids, np.uint32)
+        n = C.c_uint64()
+        self.ctx.check(lib().shz_table_delete_songs(self.h, ptr(a), len(a), C.byref(n)))
+        return int(n.value)
+
+    def clear(self):
+        self.ctx.check(lib().shz_table_clear(self.h))
 
     def rows(self):
         a, b = C.c_uint64(), C.c_uint64()

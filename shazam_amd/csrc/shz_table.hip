@@ -36,6 +36,7 @@ struct shz_table {
   uint32_t* bucket = nullptr;
   uint64_t nbuckets = 0;  // bucket has nbuckets+1 entries
   uint32_t max_sid = 0, max_off = 0;
+  bool broken = false;  // a finalize ran out of memory after giving up the old columns: rows were lost, refuse further use
 };
 
 static std::vector<shz_seg> all_segs(const shz_table* t) {
@@ -456,19 +457,38 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   // The old columns are dead once composed.  If they can hold the merged rows they are written in place (no
   // hipFree / hipMalloc of gigabytes per finalize: that, not the kernels, dominated incremental ingest); otherwise they
   // are freed before the new ones are allocated (peak memory), with 1/8 headroom for the next batches.
-  t->n = 0;
   if (nu > t->cap) {
-    void* olds[] = {t->key, t->sid, t->off};
-    for (void* p : olds)
-      if (p) SHZ_HIP(ctx, hipFree(p));
-    t->key = t->sid = t->off = nullptr;
-    t->cap = 0;
+    // Grow: new columns are allocated while the old ones still exist, so that running out of memory leaves the table
+    // as it was (the merged rows are in the sort workspace, nothing of the table has been touched yet).  Only if that
+    // fails are the old columns given up first (lower peak); a failure after that has lost rows and marks the table.
     const uint64_t want = std::min<uint64_t>(nu + nu / 8 + 1024, std::max<uint64_t>(nu, t->seg_limit) + 1024);
-    if (hipMalloc(&t->key, want * 4) != hipSuccess || hipMalloc(&t->sid, want * 4) != hipSuccess ||
-        hipMalloc(&t->off, want * 4) != hipSuccess)
-      SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)want);
+    dev_cols fresh;
+    if (!fresh.alloc(want)) {
+      for (int i = 0; i < 3; ++i)
+        if (uint32_t* q = fresh.take(i)) (void)hipFree(q);
+      (void)hipGetLastError();
+      void* olds[] = {t->key, t->sid, t->off};
+      for (void* p : olds)
+        if (p) (void)hipFree(p);
+      t->key = t->sid = t->off = nullptr;
+      t->cap = 0;
+      t->n = 0;
+      if (!fresh.alloc(want)) {
+        t->broken = true;
+        SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed after the active segment was released; "
+                                   "the table lost rows and refuses further use", (unsigned long long)want);
+      }
+    } else {
+      void* olds[] = {t->key, t->sid, t->off};
+      for (void* p : olds)
+        if (p) SHZ_HIP(ctx, hipFree(p));
+    }
+    t->key = fresh.take(0);
+    t->sid = fresh.take(1);
+    t->off = fresh.take(2);
     t->cap = want;
   }
+  t->n = 0;
   uint32_t *nk = t->key, *nsid = t->sid, *noff = t->off;
   if (one_key)
     hipLaunchKernelGGL(tbl_compact1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -498,6 +518,194 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
 }
 
 
+// ---- rows leaving the table: ON DELETE CASCADE of a song's fingerprints (mysql_database.py:57-58), and INSERT IGNORE
+// against rows that already sit in a frozen segment (UNIQUE(song_id, offset, hash), :54-55, 62-68) ----
+__global__ void tbl_sid_keep_kernel(const uint32_t* __restrict__ sid, uint64_t n, const uint32_t* __restrict__ bitmap,
+                                    uint32_t nbits, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = sid[i];
+  flag[i] = (s < nbits && ((bitmap[s >> 5] >> (s & 31)) & 1u)) ? 0u : 1u;
+}
+__global__ void tbl_gather_u32_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flag,
+                                      const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) out[pos[i]] = in[i];
+}
+__global__ void tbl_ones_kernel(uint32_t* __restrict__ flag, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = 1u;
+}
+// flag[i] = 0 where staged row i is a row of the (sorted, unique) segment g
+__global__ void tbl_exists_kernel(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ ssid,
+                                  const uint32_t* __restrict__ soff, uint64_t ns, shz_seg_dev g,
+                                  uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns || !flag[i]) return;
+  const uint32_t k = skey[i], sd = ssid[i], of = soff[i];
+  const uint64_t b = k >> 8;
+  if (b >= g.nbuckets) return;
+  uint32_t lo = g.bucket[b], hi = g.bucket[b + 1];
+  while (lo < hi) {  // first row >= (k, sd, of)
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    const uint32_t mk = g.key[mid];
+    bool less = mk < k;
+    if (mk == k) {
+      const uint32_t ms = g.sid[mid];
+      less = ms < sd || (ms == sd && g.off[mid] < of);
+    }
+    if (less) lo = mid + 1; else hi = mid;
+  }
+  if (lo < g.n && g.key[lo] == k && g.sid[lo] == sd && g.off[lo] == of) flag[i] = 0u;
+}
+
+// keep the flagged rows of three columns, in order, in place (through a scratch column); returns the kept count
+static int32_t compact_cols(shz_ctx* ctx, uint32_t* key, uint32_t* sid, uint32_t* off, uint64_t n, const uint32_t* fl,
+                            uint64_t* kept_out) {
+  void *ps, *tot, *tmp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n * 4, &ps));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
+  SHZ_TRY(shz_scan_u32(ctx, fl, (uint32_t*)ps, n, (uint64_t*)tot));
+  uint64_t kept = 0;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &kept, tot, 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *kept_out = kept;
+  if (kept == n || n == 0) return SHZ_OK;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, std::max<uint64_t>(kept, 1) * 4, &tmp));
+  uint32_t* cols[3] = {key, sid, off};
+  for (uint32_t* c : cols) {
+    hipLaunchKernelGGL(tbl_gather_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)c, fl, (const uint32_t*)ps, n, (uint32_t*)tmp);
+    SHZ_HIP(ctx, hipGetLastError());
+    if (kept) SHZ_HIP(ctx, hipMemcpyAsync(c, tmp, kept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+// bucket index of a sorted segment whose rows changed
+static int32_t rebuild_buckets(shz_ctx* ctx, uint32_t* key, uint64_t n, uint32_t** bucket, uint64_t* nbuckets, uint64_t* bcap) {
+  if (n == 0) { *nbuckets = 0; return SHZ_OK; }
+  uint32_t last_key = 0;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &last_key, key + (n - 1), 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t nb = (uint64_t)(last_key >> 8) + 1;
+  if (nb + 1 > *bcap) {
+    if (*bucket) SHZ_HIP(ctx, hipFree(*bucket));
+    *bucket = nullptr;
+    *bcap = 0;
+    SHZ_HIP(ctx, hipMalloc(bucket, (nb + 1) * 4));
+    *bcap = nb + 1;
+  }
+  *nbuckets = nb;
+  hipLaunchKernelGGL(tbl_bucket_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)key, (uint32_t)n, nb, *bucket);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, uint64_t n_sids, uint64_t* rows_deleted) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (rows_deleted) *rows_deleted = 0;
+  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  if (n_sids == 0) return SHZ_OK;
+  if (!sids) SHZ_FAIL(ctx, SHZ_E_INVALID, "sids is NULL");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t mx = 0;
+  for (uint64_t i = 0; i < n_sids; ++i) mx = std::max(mx, sids[i]);
+  const uint32_t nbits = mx + 1;
+  std::vector<uint32_t> bm(((uint64_t)nbits + 31) / 32, 0u);
+  for (uint64_t i = 0; i < n_sids; ++i) bm[sids[i] >> 5] |= 1u << (sids[i] & 31);
+  void* d_bm;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, bm.size() * 4, &d_bm));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_bm, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t gone = 0;
+  auto purge = [&](uint32_t* key, uint32_t* sid, uint32_t* off, uint64_t n, uint64_t* kept) -> int32_t {
+    void* fl;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, std::max<uint64_t>(n, 1) * 4, &fl));
+    hipLaunchKernelGGL(tbl_sid_keep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)sid, n, (const uint32_t*)d_bm, nbits, (uint32_t*)fl);
+    SHZ_HIP(ctx, hipGetLastError());
+    return compact_cols(ctx, key, sid, off, n, (const uint32_t*)fl, kept);
+  };
+  for (shz_seg& g : t->done) {
+    uint64_t kept = g.n, bcap = g.nbuckets + 1;
+    SHZ_TRY(purge(g.key, g.sid, g.off, g.n, &kept));
+    if (kept != g.n) {
+      gone += g.n - kept;
+      g.n = kept;
+      SHZ_TRY(rebuild_buckets(ctx, g.key, g.n, &g.bucket, &g.nbuckets, &bcap));
+    }
+  }
+  // frozen segments that became empty disappear
+  for (size_t i = t->done.size(); i-- > 0;)
+    if (t->done[i].n == 0) {
+      void* qs[] = {t->done[i].key, t->done[i].sid, t->done[i].off, t->done[i].bucket};
+      for (void* p : qs)
+        if (p) (void)hipFree(p);
+      t->done.erase(t->done.begin() + (long)i);
+    }
+  if (t->n) {
+    uint64_t kept = t->n;
+    SHZ_TRY(purge(t->key, t->sid, t->off, t->n, &kept));
+    if (kept != t->n) {
+      gone += t->n - kept;
+      t->n = kept;
+      SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap));
+    }
+  }
+  if (t->ns) {
+    uint64_t kept = t->ns;
+    SHZ_TRY(purge(t->skey, t->ssid, t->soff, t->ns, &kept));
+    gone += t->ns - kept;
+    t->ns = kept;
+  }
+  if (rows_deleted) *rows_deleted = gone;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_clear(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (shz_seg& g : t->done) {
+    void* qs[] = {g.key, g.sid, g.off, g.bucket};
+    for (void* p : qs)
+      if (p) (void)hipFree(p);
+  }
+  t->done.clear();
+  t->n = 0;        // the active and staging columns keep their allocations for the rows to come
+  t->nbuckets = 0;
+  t->ns = 0;
+  t->max_sid = t->max_off = 0;
+  t->broken = false;
+  return SHZ_OK;
+}
+
+// INSERT IGNORE across segments: staged rows that already sit in a frozen segment are dropped before they are merged
+static int32_t drop_staged_duplicates_of_frozen(shz_table* t) {
+  shz_ctx* ctx = t->ctx;
+  if (t->done.empty() || t->ns == 0) return SHZ_OK;
+  void* fl;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, t->ns * 4, &fl));
+  hipLaunchKernelGGL(tbl_ones_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)fl, t->ns);
+  for (const shz_seg& g : t->done) {
+    if (!g.n) continue;
+    shz_seg_dev gd{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets};
+    hipLaunchKernelGGL(tbl_exists_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, gd, (uint32_t*)fl);
+  }
+  SHZ_HIP(ctx, hipGetLastError());
+  uint64_t kept = t->ns;
+  SHZ_TRY(compact_cols(ctx, t->skey, t->ssid, t->soff, t->ns, (const uint32_t*)fl, &kept));
+  t->ns = kept;
+  return SHZ_OK;
+}
+
 static void freeze_active(shz_table* t) {
   if (!t->n) return;
   t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
@@ -510,6 +718,9 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   if (!t) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  if (t->ns && t->n + t->ns > t->seg_limit) freeze_active(t);   // the staged rows start new segment(s)
+  SHZ_TRY(drop_staged_duplicates_of_frozen(t));                  // UNIQUE(song_id, offset, hash) across segments
   if (t->ns == 0) {
     if (!t->bucket && t->n == 0 && t->done.empty()) {  // empty table: one empty bucket
       SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
@@ -523,8 +734,7 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   // inside one batch are still removed), one new segment per slice
   if (t->n + t->ns <= t->seg_limit) {
     SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns));
-  } else {
-    freeze_active(t);
+  } else {   // t->n == 0 here: the active segment was frozen above
     const uint32_t nsl = (uint32_t)((t->ns + t->seg_limit - 1) / t->seg_limit) + (t->ns > t->seg_limit ? 1 : 0);
     if (t->done.size() + nsl > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
     for (uint32_t sl = 0; sl < nsl; ++sl) {

@@ -27,8 +27,10 @@ class _Cursor:
         self.rows = []
         if q.startswith("SELECT HEX(`HASH`)") and " IN (" in q:          # SELECT_MULTIPLE
             self.rows = self.db._select_multiple(list(values))
-        elif q.startswith("CREATE TABLE") or q.startswith("DROP TABLE"):
+        elif q.startswith("CREATE TABLE"):
             pass
+        elif q.startswith("DROP TABLE"):       # empty() of the reference drops both tables (mysql_database.py:143-153)
+            self.db.drop_table("songs" if "SONGS" in q else "fingerprints")
         elif q.startswith("DELETE FROM `SONGS` WHERE `FINGERPRINTED` = 0"):  # DELETE_UNFINGERPRINTED
             self.db.delete_unfingerprinted()
         else:
@@ -102,10 +104,28 @@ class HipFingerprintDB:
         self.songs[song_id]["fingerprinted"] = 1
 
     def delete_unfingerprinted(self):
-        """DELETE_UNFINGERPRINTED (mysql_database.py:132-134).  Rows of such songs stay in the device
-        table but can never be returned by get_songs; a rebuild drops them."""
-        for sid in [s for s, v in self.songs.items() if not v["fingerprinted"]]:
-            del self.songs[sid]
+        """DELETE_UNFINGERPRINTED (mysql_database.py:132-134) with the schema's ON DELETE CASCADE (:57-58): songs whose
+        ingest never reached set_song_fingerprinted disappear together with their fingerprint rows, so a later match
+        can neither return them nor spend a top-n slot on them."""
+        gone = [s for s, v in self.songs.items() if not v["fingerprinted"]]
+        if gone:
+            self.table.delete_songs(gone)
+            for sid in gone:
+                del self.songs[sid]
+
+    def drop_table(self, which: str):
+        """DROP TABLE IF EXISTS `songs` / `fingerprints` (DROP_SONGS / DROP_FINGERPRINTS, mysql_database.py:143-153)."""
+        if which == "songs":
+            self.songs.clear()
+            self._next_sid = 1
+        self.table.clear()       # fingerprints reference songs ON DELETE CASCADE: either drop empties them
+        self._dirty = False
+
+    def empty(self):
+        """MySQLDatabase.empty(): drop both tables and set them up again."""
+        self.drop_table("fingerprints")
+        self.drop_table("songs")
+        self.setup()
 
     def get_songs(self):
         """SELECT_SONGS rows: (song_id, song_name, HEX(file_sha1), total_hashes, date_created)."""

@@ -131,6 +131,14 @@ class ShardedTable:
             for t in self.tables:
                 t.finalize()
 
+    def delete_songs(self, sids) -> int:
+        """ON DELETE CASCADE on every shard held here (with a communicator: call it on every rank)."""
+        return sum(t.delete_songs(sids) for t in self.tables)
+
+    def clear(self):
+        for t in self.tables:
+            t.clear()
+
     def rows(self):
         """(rows held here, staged rows held here)"""
         r = [t.rows() for t in self.tables]
