@@ -110,12 +110,18 @@ extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
   }
   for (int i = 0; i < SHZ_NFFT; ++i) sumsq += win[i] * win[i];
   ctx->win_sumsq = sumsq;
-  std::vector<double2> tw(SHZ_NFFT / 4 + 1);
-  for (int k = 0; k <= SHZ_NFFT / 4; ++k) {
-    long double a = -2.0L * pi * (long double)k / (long double)SHZ_NFFT;
-    tw[k].x = (double)cosl(a);
-    tw[k].y = (double)sinl(a);
-  }
+  // twiddles of the 2048-point FFT (layout: stft_tables in shz_extract.hip): W^k for k <= 512 (the other octants by
+  // symmetry), then W_64^(k t) for pass 2 ([t-1][k], k < 8) and W_512^(k t) for pass 3 ([t-1][k], k < 64), t = 1..7
+  std::vector<double2> tw;
+  auto W = [&](long m) {  // W4096^m
+    const long double a = -2.0L * pi * (long double)(m % SHZ_NFFT) / (long double)SHZ_NFFT;
+    return double2{(double)cosl(a), (double)sinl(a)};
+  };
+  for (int k = 0; k <= SHZ_NFFT / 8; ++k) tw.push_back(W(k));
+  for (int t = 1; t < 8; ++t)
+    for (int k = 0; k < 8; ++k) tw.push_back(W(64L * k * t));
+  for (int t = 1; t < 8; ++t)
+    for (int k = 0; k < 64; ++k) tw.push_back(W(8L * k * t));
   std::vector<int16_t> lut(4096);
   for (int i = 0; i < 4096; ++i) lut[i] = (int16_t)lrint(32767.0 * sin(2.0 * M_PI * (double)i / 4096.0));
   bool ok = hipMalloc(&ctx->d_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&

@@ -31,6 +31,14 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ cplx cmul_negi(cplx a) { return make_double2(a.y, -a.x); }  // a * (-i)
+// c ? a : b as four 32-bit selects.  Written on the halves so that the compiler keeps the operands in registers: with
+// plain `c ? a : b` on eight live complex values it parks them in scratch and selects by address.
+__device__ __forceinline__ double dsel(bool c, double a, double b) {
+  const int lo = c ? __double2loint(a) : __double2loint(b);
+  const int hi = c ? __double2hiint(a) : __double2hiint(b);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cplx csel(bool c, cplx a, cplx b) { return make_double2(dsel(c, a.x, b.x), dsel(c, a.y, b.y)); }
 
 __device__ __forceinline__ void dft4(cplx& c0, cplx& c1, cplx& c2, cplx& c3) {
   cplx d0 = cadd(c0, c2), d2 = csub(c0, c2), d1 = cadd(c1, c3), d3 = cmul_negi(csub(c1, c3));
@@ -86,16 +94,39 @@ struct stft_args {
 // 1e-7 of the amp_min threshold -- goes to peak_verify_kernel, which recomputes the fp64 values of just those cells
 // with the arithmetic of this kernel (stft_frame below is the one definition of it).
 
-#define LDS_CPLX (2048 + 1025 + 16 + 128)
+#define TW_MAIN 513                        // W4096^k, k in [0, 512]
+#define TW_P2 (7 * 8)                      // pass 2: [t-1][k] = W_64^(k t)
+#define TW_P3 (7 * 64)                     // pass 3: [t-1][k] = W_512^(k t)
+#define TW_ALL (TW_MAIN + TW_P2 + TW_P3)   // entries of ctx->d_twiddle (shz_ctx.hip)
+#define LDS_CPLX (2048 + TW_ALL)
 
-// twiddle tables into LDS (tw: W4096^k, k <= 1024; tw2/tw3: contiguous copies for passes 2 and 3, no bank conflicts)
+// twiddle tables into LDS
 __device__ __forceinline__ void stft_tables(cplx* lds, const cplx* gtw, int j, int nthreads) {
-  cplx* tw = lds + 2048;
-  cplx* tw2 = tw + 1025;
-  cplx* tw3 = tw2 + 16;
-  for (int i = j; i < 1025; i += nthreads) tw[i] = gtw[i];
-  if (j < 8) { tw2[j] = gtw[64 * j]; tw2[8 + j] = gtw[128 * j]; }
-  if (j < 64) { tw3[j] = gtw[8 * j]; tw3[64 + j] = gtw[16 * j]; }
+  for (int i = j; i < TW_ALL; i += nthreads) lds[2048 + i] = gtw[i];
+}
+// W^(1024 - k) from W^k = (c, s):  W^1024 conj(W^k) = -i (c, -s) = (-s, -c)
+__device__ __forceinline__ cplx tw_mirror(cplx w) { return make_double2(-w.y, -w.x); }
+
+// forward 8-point DFT, in place, natural output order.  The factor sqrt(1/2) of the rotations W8^1, W8^3 is not applied
+// to the rotated terms but folded into the additions that consume them (fma), four multiplications less.
+__device__ __forceinline__ void dft8f(cplx* v) {
+  const double s = 0.70710678118654752440;
+  cplx b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
+  cplx b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
+  cplx b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
+  cplx b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
+  dft4(b0, b1, b2, b3);
+  // odd half: p5 = sqrt2 b5 W8^1, p7 = sqrt2 b7 W8^3 (unscaled), b6 W8^2 = -i b6
+  const cplx p5 = make_double2(b5.x + b5.y, b5.y - b5.x);
+  const cplx p7 = make_double2(b7.y - b7.x, -(b7.x + b7.y));
+  b6 = cmul_negi(b6);
+  const cplx d0 = cadd(b4, b6), d2 = csub(b4, b6);
+  const cplx q1 = cadd(p5, p7), q3 = cmul_negi(csub(p5, p7));
+  const cplx c0 = make_double2(fma(s, q1.x, d0.x), fma(s, q1.y, d0.y));
+  const cplx c2 = make_double2(fma(-s, q1.x, d0.x), fma(-s, q1.y, d0.y));
+  const cplx c1 = make_double2(fma(s, q3.x, d2.x), fma(s, q3.y, d2.y));
+  const cplx c3 = make_double2(fma(-s, q3.x, d2.x), fma(-s, q3.y, d2.y));
+  v[0] = b0; v[1] = c0; v[2] = b1; v[3] = c1; v[4] = b2; v[5] = c2; v[6] = b3; v[7] = c3;
 }
 
 // PCM of frame `g` (sub-batch numbering) of clip `lo` as 8 packed sample pairs per thread
@@ -132,56 +163,53 @@ __device__ __forceinline__ void stft_load_frame(const stft_args& a, uint32_t lo,
 // `before_out()` runs between the last butterflies and the outputs (the persistent kernel issues the next frame's
 // loads there); `out(k, p)` receives every bin k once with its scaled power p (exact zero already mapped to 1.0).
 // Ends with a barrier: buf may be rewritten on return.
+// value staged for a bin: the power itself, an exact zero as 1.0 (see the comment above stft_args).  The test reads
+// the bits (p >= 0: zero <=> no bit set), two 32-bit operations instead of an fp64 compare and a 64-bit select.
+template <typename T>
+__device__ __forceinline__ T stage_value(double p) {
+  return ((__double2hiint(p) | __double2loint(p)) != 0) ? (T)p : (T)1.0;
+}
+
+// One frame: windowed samples v[8] (complex point j + 256 t = samples 2n, 2n+1) -> power of the 2049 bins.
+// `before_out()` runs between the last butterflies and the outputs (the persistent kernel issues the next frame's
+// loads there); `out(k, p)` receives every bin k once with its scaled power p (>= 0; stage_value maps it).
+// Ends with a barrier: buf may be rewritten on return.
 template <class PRE, class OUT>
 __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, double scale, PRE&& before_out, OUT&& out) {
   cplx* buf = lds;
   const cplx* tw = lds + 2048;
-  const cplx* tw2 = tw + 1025;
-  const cplx* tw3 = tw2 + 16;
+  const cplx* tw2 = tw + TW_MAIN;
+  const cplx* tw3 = tw2 + TW_P2;
   const int sw = (j >> 3) & 7;  // swizzle term of element j + 256 t
   // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
-  dft8(v);
+  dft8f(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[(8 * j + r) ^ (j & 7)] = v[r];
   __syncthreads();
 
-  // pass 2: Ns = 8, twiddles W_64^(k t) = W4096^(64 k t)
+  // pass 2: Ns = 8, twiddles W_64^(k t) from the table (seven 16-byte reads instead of two reads and five complex products)
   {
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
     __syncthreads();
     const int k = j & 7;
-    const cplx w1 = tw2[k], w2 = tw2[8 + k];
-    const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
-    v[1] = cmul(v[1], w1);
-    v[2] = cmul(v[2], w2);
-    v[3] = cmul(v[3], w3);
-    v[4] = cmul(v[4], w4);
-    v[5] = cmul(v[5], cmul(w1, w4));
-    v[6] = cmul(v[6], cmul(w2, w4));
-    v[7] = cmul(v[7], cmul(w3, w4));
-    dft8(v);
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw2[(t - 1) * 8 + k]);
+    dft8f(v);
     const int base = ((j >> 3) << 6) + k;
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf[(base + 8 * r) ^ r] = v[r];  // ((base + 8r) >> 3) & 7 == r
     __syncthreads();
   }
-  // pass 3: Ns = 64, twiddles W_512^(k t) = W4096^(8 k t)
+  // pass 3: Ns = 64, twiddles W_512^(k t)
   {
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
     __syncthreads();
     const int k = j & 63;
-    const cplx w1 = tw3[k], w2 = tw3[64 + k];
-    const cplx w3 = cmul(w1, w2), w4 = cmul(w2, w2);
-    v[1] = cmul(v[1], w1);
-    v[2] = cmul(v[2], w2);
-    v[3] = cmul(v[3], w3);
-    v[4] = cmul(v[4], w4);
-    v[5] = cmul(v[5], cmul(w1, w4));
-    v[6] = cmul(v[6], cmul(w2, w4));
-    v[7] = cmul(v[7], cmul(w3, w4));
-    dft8(v);
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw3[(t - 1) * 64 + k]);
+    dft8f(v);
     const int base = ((j >> 6) << 9) + k;
     const int ks = (k >> 3) & 7;
 #pragma unroll
@@ -193,60 +221,73 @@ __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, doubl
   // Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
   // thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
   // b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
+  // Twiddles: butterfly 512 - j uses W^(1024 - 2j) and its powers, mirrors of butterfly j's (tw_mirror): W1' = -i conj(W1),
+  // W2' = -conj(W2), W3' = i conj(W3); the post-pass needs W^j, W^(512-j) and their mirrors W^(1024-j), W^(512+j).
+  // Thread 0's second butterfly is b = 256, not 512: its twiddles are constants, selected below.
   {
-    const int bb = j ? 512 - j : 256;
+    const bool t0 = j == 0;
+    const int bb = t0 ? 256 : 512 - j;
     const int swb = (bb >> 3) & 7;
     cplx A0 = buf[j ^ sw], A1 = buf[(j + 512) ^ sw], A2 = buf[(j + 1024) ^ sw], A3 = buf[(j + 1536) ^ sw];
     cplx B0 = buf[bb ^ swb], B1 = buf[(bb + 512) ^ swb], B2 = buf[(bb + 1024) ^ swb], B3 = buf[(bb + 1536) ^ swb];
+    const double h = 0.70710678118654752440;
     {
       const cplx w1 = tw[2 * j];
       const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+      // b = 256: W^512 = (h, -h), W^1024 = (0, -1), W^1536 = (-h, -h)
+      const cplx v1 = csel(t0, make_double2(h, -h), tw_mirror(w1));
+      const cplx v2 = csel(t0, make_double2(0.0, -1.0), make_double2(-w2.x, w2.y));
+      const cplx v3 = csel(t0, make_double2(-h, -h), make_double2(w3.y, w3.x));
       A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
       dft4(A0, A1, A2, A3);
-    }
-    {
-      const cplx w1 = tw[2 * bb];
-      const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-      B1 = cmul(B1, w1); B2 = cmul(B2, w2); B3 = cmul(B3, w3);
+      B1 = cmul(B1, v1); B2 = cmul(B2, v2); B3 = cmul(B3, v3);
       dft4(B0, B1, B2, B3);
     }
     before_out();
     const double scale2 = scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
-    // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024]
-    auto pair_out = [&](int k, cplx zk, cplx zm) {
+    // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024], wk = W^k
+    auto pair_out = [&](int k, cplx wk, cplx zk, cplx zm) {
       const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
       const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
-      const cplx wo = cmul(tw[k], o);
+      const cplx wo = cmul(wk, o);
       const cplx xa = cadd(e, wo), xb = csub(e, wo);
       const double sc = (k != 0) ? scale2 : scale;  // bin 2048 pairs with k = 0: both unscaled
       const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
       const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
-      out(k, (pa != 0.0) ? pa : 1.0);
-      if (k != 1024) out(2048 - k, (pb != 0.0) ? pb : 1.0);
+      out(k, pa);
+      if (k != 1024) out(2048 - k, pb);
     };
     // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
     // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
-    const bool t0 = j == 0;
-    pair_out(t0 ? 256 : 512 - j, B0, t0 ? B3 : A3);   // ordered so that each pair frees its operands early
-    pair_out(j, A0, t0 ? A0 : B3);
-    pair_out(j + 512, A1, t0 ? A3 : B2);
-    pair_out(t0 ? 768 : 1024 - j, B1, t0 ? B2 : A2);
-    if (t0) pair_out(1024, A2, A2);
+    const cplx wj = tw[j], wa = tw[bb];                                  // W^j, W^(512-j)   [thread 0: W^0, W^256]
+    const cplx wma = tw_mirror(wa);                                      // W^(512+j)        [thread 0: W^768]
+    const cplx w3rd = csel(t0, make_double2(h, -h), wma);                // k = j + 512      [thread 0: W^512]
+    const cplx w4th = csel(t0, wma, tw_mirror(wj));                      // k = 1024 - j     [thread 0: W^768]
+    pair_out(bb, wa, B0, csel(t0, B3, A3));   // ordered so that each pair frees its operands early
+    pair_out(j, wj, A0, csel(t0, A0, B3));
+    pair_out(j + 512, w3rd, A1, csel(t0, A3, B2));
+    pair_out(t0 ? 768 : 1024 - j, w4th, B1, csel(t0, B2, A2));
+    if (t0) pair_out(1024, make_double2(0.0, -1.0), A2, A2);
   }
   __syncthreads();  // buf is rewritten by the next frame's pass 1
 }
 
 #define P32_STRIDE 2064  // floats per fp32 row: 2049 bins padded so every row starts 64-byte aligned
+#ifndef STFT_OCC
+#define STFT_OCC 3
+#endif
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
+__global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   __shared__ cplx lds[LDS_CPLX];
   const int j = threadIdx.x;
   stft_tables(lds, a.tw, j, 256);
   __syncthreads();
   constexpr uint32_t STRIDE = sizeof(T) == 8 ? DB_STRIDE : P32_STRIDE;
 
-  // the Hann window values this thread multiplies with are the same for every frame: registers
+  // the Hann window values this thread multiplies with are the same for every frame: registers.  (Re-reading them per
+  // frame -- 32 KB per workgroup from L2 -- frees 32 registers, 8 spilled instead of 24, and costs 4.73 ms against 4.38:
+  // the loads sit at the head of the frame's dependency chain.)
   double2 ww[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.window + 2 * (j + 256 * t));
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void stft_psd_kernel(stft_args a) {
     T* orow = reinterpret_cast<T*>(a.out) + (uint64_t)g * STRIDE;
     stft_frame(
         v, lds, j, a.scale, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
-        [&](int k, double p) { orow[k] = (T)p; });
+        [&](int k, double p) { orow[k] = stage_value<T>(p); });
   }
 }
 
