@@ -162,7 +162,10 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
     out["db_build"] = {"rows": int(rows), "songs": world * nc, "seconds_table_only": t_build,
                        "seconds_incl_fingerprint": t_build + elapsed / a.steps,
                        "songs_per_second_incl_fingerprint": world * nc / (t_build + elapsed / a.steps),
-                       "allgather_bytes_received": int(recv), "collective": "rccl grouped broadcast (all-gather-v)" if comm else None}
+                       "allgather_bytes_received": int(recv),
+                       "collective": (f"RCCL all-gather-v of the ranks' sorted packed runs (8 B/row, pieces <= 1 GB, "
+                                      f"pattern {os.environ.get('SHZ_ALLGATHER', 'sendrecv')}), then {world}-way merge") if comm else None,
+                       "build_stats_s": tbl.build_stats() if comm else None}
     # batched recognise: hop-aligned 5 s crops of this rank's own tracks (clean; SNR mixing is a test-side path)
     nq = min(a.queries, nc)
     qn = 220500

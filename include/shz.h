@@ -228,9 +228,20 @@ int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, u
 int32_t shz_comm_unique_id(uint8_t id_out[128]);
 int32_t shz_comm_create(shz_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t nranks, shz_comm** out);
 int32_t shz_comm_destroy(shz_comm* c);
-/* all-gather every rank's STAGED rows over RCCL/xGMI, then finalize: afterwards every rank
- * holds the same node-global table.  bytes_recv: payload bytes this rank received. */
+/* All-gather every rank's STAGED rows over RCCL/xGMI into the node-global table: afterwards every rank holds the
+ * same table.  Into an empty table (the database build) every rank sorts its own rows, the sorted runs travel packed
+ * at 8 bytes a row in pieces of <= 1 GB (SHZ_ALLGATHER=sendrecv (default, explicit mesh) | bcast selects the
+ * pattern), and every rank merges the nranks runs (log2 nranks merge-path passes) and cuts segments -- no rank sorts
+ * other ranks' rows again.  Otherwise (table not empty, or song id + offset wider than 32 bits, or
+ * SHZ_ALLGATHER=columns) the unsorted columns travel and finalize sorts everything.
+ * bytes_recv: payload bytes this rank received. */
 int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv);
+/* The sort + merge + segments half of the above without a communicator: the staged rows are n_runs consecutive
+ * blocks of run_rows[r] rows (what n_runs ranks would have staged); the result equals shz_table_finalize's. */
+int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_rows, uint32_t n_runs);
+/* seconds the last shz_table_allgather / shz_table_finalize_runs spent sorting its own rows, exchanging, merging
+ * the runs and cutting segments (host clock around stream syncs).  Any pointer may be NULL. */
+int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, double* merge_s, double* segments_s);
 int32_t shz_comm_barrier(shz_comm* c);
 
 /* ---- key-sharded table (new; SURVEY.md 8f row 4: the table no longer fits one GPU) -------

@@ -72,6 +72,9 @@ SIGNATURES = {
     "shz_comm_create": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "shz_comm_destroy": (C.c_int32, [vp]),
     "shz_table_allgather": (C.c_int32, [vp, vp, u64p]),
+    "shz_table_finalize_runs": (C.c_int32, [vp, u64p, C.c_uint32]),
+    "shz_table_build_stats": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]),
     "shz_comm_barrier": (C.c_int32, [vp]),
     "shz_shard_of_keys": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp]),
     "shz_table_keep_shard": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
@@ -472,6 +475,17 @@ class Table:
         n = C.c_uint64()
         self.ctx.check(lib().shz_table_song_rows(self.h, int(sid), C.byref(n)))
         return n.value
+
+    def finalize_runs(self, run_rows):
+        """finalize() for staged rows that are consecutive blocks of run_rows[r] rows: every block is sorted on its own
+        and the sorted runs are merged -- what allgather() does with the ranks' rows, without a communicator."""
+        rr = np.ascontiguousarray(run_rows, np.uint64)
+        self.ctx.check(lib().shz_table_finalize_runs(self.h, rr.ctypes.data_as(u64p), len(rr)))
+
+    def build_stats(self) -> dict:
+        v = [C.c_double() for _ in range(4)]
+        self.ctx.check(lib().shz_table_build_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("sort_s", "exchange_s", "merge_s", "segments_s"), (float(x.value) for x in v)))
 
     def allgather(self, comm: "Comm") -> int:
         b = C.c_uint64()

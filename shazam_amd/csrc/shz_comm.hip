@@ -3,6 +3,8 @@
 // travels between ranks through the host (torch.distributed store / any side channel).
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include "shz_internal.h"
 
 typedef struct ncclComm* ncclComm_t;
@@ -115,19 +117,45 @@ int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, 
   return SHZ_OK;
 }
 
-// variable-size all-gather as one grouped set of broadcasts: rank r's block lands at
-// d_recv + displ[r]; every peer pair moves data directly (mesh over xGMI, no ring staging).
+// Variable-size all-gather: rank r's block lands at d_recv + displ[r] on every rank.  Moved in pieces of <= 1 GB
+// (SURVEY 8e), each piece one RCCL group in which all ranks' transfers are in flight together, so that every pair of
+// GPUs uses its own xGMI link instead of a ring bound by one link.  Two exchange patterns, selected by SHZ_ALLGATHER:
+//   sendrecv (default)  every rank ncclSend-s its piece to each peer and ncclRecv-s each peer's piece: an explicit mesh
+//   bcast               one ncclBroadcast per root
+// Whatever fails inside a group, the group is closed before the error is returned.
 int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
                                   const uint64_t* displ) {
   shz_ctx* ctx = c->ctx;
   rccl_api* r = rccl();
-  if (r->GroupStart) SHZ_NCCL(ctx, r->GroupStart());
-  for (int p = 0; p < c->nranks; ++p) {
-    if (counts[p] == 0) continue;
-    const void* src = (p == c->rank) ? d_send : (const void*)((char*)d_recv + displ[p]);
-    SHZ_NCCL(ctx, r->Broadcast(src, (char*)d_recv + displ[p], counts[p], NCCL_U8, p, c->comm, ctx->stream));
+  static const bool use_bcast = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "bcast"); }();
+  const uint64_t PIECE = 1ull << 30;
+  uint64_t longest = 0;
+  for (int p = 0; p < c->nranks; ++p) longest = std::max(longest, counts[p]);
+  if (counts[c->rank])   // the rank's own block: a device copy
+    SHZ_HIP(ctx, shz_memcpy(ctx, (char*)d_recv + displ[c->rank], d_send, counts[c->rank], hipMemcpyDeviceToDevice));
+  if (c->nranks == 1) return SHZ_OK;
+  if (!r->GroupStart || !r->GroupEnd) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclGroupStart/End");
+  if (!use_bcast && (!r->Send || !r->Recv)) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclSend/ncclRecv");
+  for (uint64_t o = 0; o < longest; o += PIECE) {
+    ncclResult_t bad = (ncclResult_t)0;
+    const char* what = "";
+    auto step = [&](ncclResult_t rc, const char* w) { if (rc != 0 && bad == 0) { bad = rc; what = w; } };
+    step(r->GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < c->nranks && bad == 0; ++p) {
+      const uint64_t mine = counts[c->rank] > o ? std::min(PIECE, counts[c->rank] - o) : 0;
+      const uint64_t theirs = counts[p] > o ? std::min(PIECE, counts[p] - o) : 0;
+      if (use_bcast) {
+        if (!theirs) continue;
+        char* dst = (char*)d_recv + displ[p] + o;
+        step(r->Broadcast(dst, dst, theirs, NCCL_U8, p, c->comm, ctx->stream), "ncclBroadcast");   // in place: root holds it
+      } else if (p != c->rank) {
+        if (mine) step(r->Send((const char*)d_send + o, mine, NCCL_U8, p, c->comm, ctx->stream), "ncclSend");
+        if (theirs) step(r->Recv((char*)d_recv + displ[p] + o, theirs, NCCL_U8, p, c->comm, ctx->stream), "ncclRecv");
+      }
+    }
+    step(r->GroupEnd(), "ncclGroupEnd");
+    if (bad != 0) SHZ_FAIL(ctx, SHZ_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(bad) : "rccl error");
   }
-  if (r->GroupEnd) SHZ_NCCL(ctx, r->GroupEnd());
   return SHZ_OK;
 }
 
@@ -145,13 +173,17 @@ int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t
                                 hipMemcpyDeviceToDevice));
   if (c->nranks == 1) return SHZ_OK;
   if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclSend/ncclRecv");
-  SHZ_NCCL(ctx, r->GroupStart());
-  for (int p = 0; p < c->nranks; ++p) {
+  ncclResult_t bad = (ncclResult_t)0;
+  const char* what = "";
+  auto step = [&](ncclResult_t rc, const char* w) { if (rc != 0 && bad == 0) { bad = rc; what = w; } };
+  step(r->GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < c->nranks && bad == 0; ++p) {
     if (p == c->rank) continue;
-    if (scount[p]) SHZ_NCCL(ctx, r->Send((const char*)d_send + sdispl[p], scount[p], NCCL_U8, p, c->comm, ctx->stream));
-    if (rcount[p]) SHZ_NCCL(ctx, r->Recv((char*)d_recv + rdispl[p], rcount[p], NCCL_U8, p, c->comm, ctx->stream));
+    if (scount[p]) step(r->Send((const char*)d_send + sdispl[p], scount[p], NCCL_U8, p, c->comm, ctx->stream), "ncclSend");
+    if (rcount[p]) step(r->Recv((char*)d_recv + rdispl[p], rcount[p], NCCL_U8, p, c->comm, ctx->stream), "ncclRecv");
   }
-  SHZ_NCCL(ctx, r->GroupEnd());
+  step(r->GroupEnd(), "ncclGroupEnd");   // the group is closed whatever happened inside it
+  if (bad != 0) SHZ_FAIL(ctx, SHZ_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(bad) : "rccl error");
   return SHZ_OK;
 }
 

@@ -6,6 +6,8 @@
 // Layout: three u32 column arrays sorted by (key, sid, off), duplicates removed, plus a bucket
 // index over key >> 8 (first row of every (f1, f2) prefix) so a probe is one index read and a
 // short binary search over dt.
+#include <time.h>
+
 #include <algorithm>
 
 #include "shz_internal.h"
@@ -36,6 +38,7 @@ struct shz_table {
   uint32_t* bucket = nullptr;
   uint64_t nbuckets = 0;  // bucket has nbuckets+1 entries
   uint32_t max_sid = 0, max_off = 0;
+  double bs_sort = 0, bs_exchange = 0, bs_merge = 0, bs_segments = 0;   // seconds of the last run-merge build
   bool broken = false;  // a finalize ran out of memory after giving up the old columns: rows were lost, refuse further use
 };
 
@@ -943,10 +946,214 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
 }
 
 // ---------------------------------------------------------------------------------------- all-gather build
-extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
-  if (!t || !c) return SHZ_E_INVALID;
+// ---- building a table from SORTED RUNS ("every rank merges 8 sorted runs") ---------------------------------
+// Rows travel and merge in the packed form key << (sb + ob) | sid << ob | off (8 bytes a row instead of 12; its order is
+// the table's order), which needs sid and offset to fit 32 bits together -- true for every configuration of BASELINE
+// (1M songs = 20 bits, 3-minute tracks = 12 bits).
+
+#define SHZ_I_GENERAL_PATH 1   // internal: the packed sorted-run path does not apply, take the column path
+
+// flag[i] = 1 where c[i] differs from its predecessor (prev = the element before c[0], if the chunk has one)
+__global__ void tbl_uniq1_chunk_kernel(const uint64_t* __restrict__ c, uint64_t n, bool has_prev, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = ((i == 0 && !has_prev) || c[i] != c[(int64_t)i - 1]) ? 1u : 0u;
+}
+
+// pack + sort rows [0, n) of three columns into `dst` (scratch `tmp`, both n entries)
+static int32_t pack_sort_run(shz_ctx* ctx, const uint32_t* key, const uint32_t* sid, const uint32_t* off, uint64_t n, int sb,
+                             int ob, uint64_t* dst, uint64_t* tmp) {
+  if (n == 0) return SHZ_OK;
+  if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "a run is limited to < 2^32 rows (have %llu)", (unsigned long long)n);
+  hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                     key, sid, off, n, (uint64_t)0, sb, ob, dst);
+  SHZ_HIP(ctx, hipGetLastError());
+  int sel = 0;
+  SHZ_TRY(shz_sort_u64(ctx, dst, tmp, nullptr, nullptr, 0, n, 0, 32 + sb + ob, &sel));
+  if (sel) SHZ_HIP(ctx, hipMemcpyAsync(dst, tmp, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  return SHZ_OK;
+}
+
+// merge the sorted runs run_off[r] .. run_off[r+1] of `a` pairwise, ping-ponging with `b`, until one run is left;
+// *out = the buffer that holds it
+static int32_t merge_runs(shz_ctx* ctx, uint64_t* a, uint64_t* b, std::vector<uint64_t> run_off, uint64_t** out) {
+  while (run_off.size() > 2) {
+    std::vector<uint64_t> next{0};
+    const size_t nr = run_off.size() - 1;
+    for (size_t r = 0; r < nr; r += 2) {
+      const uint64_t o0 = run_off[r], o1 = run_off[r + 1], o2 = r + 2 <= nr ? run_off[r + 2] : o1;
+      if (r + 1 == nr) {  // odd run out: carried over
+        if (o1 > o0) SHZ_HIP(ctx, hipMemcpyAsync(b + o0, a + o0, (o1 - o0) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        next.push_back(o1);
+      } else {
+        const uint64_t tot = o2 - o0;
+        if (tot) {
+          if ((tot + MERGE_TILE - 1) / MERGE_TILE >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "merge of %llu rows", (unsigned long long)tot);
+          hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((tot + MERGE_TILE - 1) / MERGE_TILE)), dim3(256), 0, ctx->stream,
+                             (const uint64_t*)(a + o0), o1 - o0, (const uint64_t*)(a + o1), o2 - o1, b + o0);
+          SHZ_HIP(ctx, hipGetLastError());
+        }
+        next.push_back(o2);
+      }
+    }
+    std::swap(a, b);
+    run_off.swap(next);
+  }
+  *out = a;
+  return SHZ_OK;
+}
+
+// an EMPTY table takes one sorted packed run of `total` rows: duplicates dropped, cut into segments of <= seg_limit rows
+static int32_t segments_from_sorted(shz_table* t, const uint64_t* g, uint64_t total, int sb, int ob) {
   shz_ctx* ctx = t->ctx;
-  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t L = std::min<uint64_t>(t->seg_limit, (1ull << 32) - 4096);
+  if ((total + L - 1) / L > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
+  for (uint64_t o = 0; o < total; o += L) {
+    const uint64_t n = std::min(L, total - o);
+    void *fl, *ps, *tot;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, n * 4, &fl));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n * 4, &ps));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
+    hipLaunchKernelGGL(tbl_uniq1_chunk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g + o, n, o > 0,
+                       (uint32_t*)fl);
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, n, (uint64_t*)tot));
+    uint64_t nu = 0;
+    SHZ_HIP(ctx, shz_memcpy(ctx, &nu, tot, 8, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nu == 0) continue;
+    if (t->n) freeze_active(t);   // the previous chunk's segment
+    dev_cols cols;
+    if (!cols.alloc(nu)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)nu);
+    t->key = cols.take(0); t->sid = cols.take(1); t->off = cols.take(2);
+    t->cap = nu;
+    hipLaunchKernelGGL(tbl_compact1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g + o,
+                       (const uint32_t*)fl, (const uint32_t*)ps, n, sb, ob, t->key, t->sid, t->off);
+    SHZ_HIP(ctx, hipGetLastError());
+    t->n = nu;
+    SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap));
+  }
+  return SHZ_OK;
+}
+
+static double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// staged rows = n_runs consecutive blocks of run_rows[r] rows: sort every block, merge the runs, build the segments.
+// With `c`, the blocks are the ranks' staged rows and travel between the sort and the merge.
+static int32_t build_from_runs(shz_table* t, shz_comm* c, const uint64_t* run_rows_in, uint32_t n_runs_in, uint64_t* bytes_recv) {
+  shz_ctx* ctx = t->ctx;
+  int rank = 0, nranks = 1;
+  if (c) shz_comm_info(c, &rank, &nranks);
+  t->bs_sort = t->bs_exchange = t->bs_merge = t->bs_segments = 0.0;
+  // maxima of this rank's staged rows
+  void* mx;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64 + 24ull * (nranks + 1), &mx));
+  SHZ_HIP(ctx, hipMemsetAsync(mx, 0, 64, ctx->stream));
+  if (t->ns)
+    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, (uint32_t*)mx);
+  SHZ_HIP(ctx, hipGetLastError());
+  uint32_t maxes[2];
+  SHZ_HIP(ctx, shz_memcpy(ctx, maxes, mx, 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // counts and maxima of every rank
+  std::vector<uint64_t> info(3 * (size_t)nranks, 0);
+  info[3 * (size_t)rank] = t->ns; info[3 * (size_t)rank + 1] = maxes[0]; info[3 * (size_t)rank + 2] = maxes[1];
+  if (c && nranks > 1) {
+    uint64_t* d_info = (uint64_t*)((char*)mx + 64);
+    SHZ_HIP(ctx, shz_memcpy(ctx, d_info, &info[3 * (size_t)rank], 24, hipMemcpyHostToDevice));
+    SHZ_TRY(shz_comm_allgather_bytes(c, d_info, d_info + 3, 24));
+    SHZ_HIP(ctx, shz_memcpy(ctx, info.data(), d_info + 3, 24ull * nranks, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  uint64_t total = 0, gmax_sid = 0, gmax_off = 0;
+  std::vector<uint64_t> cnt(nranks), displ(nranks);
+  for (int r = 0; r < nranks; ++r) {
+    cnt[r] = info[3 * (size_t)r];
+    displ[r] = total;
+    total += cnt[r];
+    gmax_sid = std::max(gmax_sid, info[3 * (size_t)r + 1]);
+    gmax_off = std::max(gmax_off, info[3 * (size_t)r + 2]);
+  }
+  if (bytes_recv) *bytes_recv = 0;
+  const int sb = bits_for(gmax_sid), ob = bits_for(gmax_off);
+  static const bool force_cols = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "columns"); }();
+  if (total == 0) return shz_table_finalize(t);
+  if (sb + ob > 32 || t->n || !t->done.empty() || force_cols) return SHZ_I_GENERAL_PATH;
+  // 1) local runs: the staged rows of this rank as sorted packed runs, back to back
+  std::vector<uint64_t> my_runs;
+  if (c) my_runs.push_back(t->ns);
+  else my_runs.assign(run_rows_in, run_rows_in + n_runs_in);
+  uint64_t sum = 0;
+  for (uint64_t r : my_runs) sum += r;
+  if (sum != t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)sum, (unsigned long long)t->ns);
+  double t0 = now_s();
+  void *pa, *pb;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, std::max<uint64_t>(t->ns, 1) * 8, &pa));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, std::max<uint64_t>(t->ns, 1) * 8, &pb));
+  uint64_t o = 0;
+  for (uint64_t r : my_runs) {
+    SHZ_TRY(pack_sort_run(ctx, t->skey + o, t->ssid + o, t->soff + o, r, sb, ob, (uint64_t*)pa + o, (uint64_t*)pb + o));
+    o += r;
+  }
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->bs_sort = now_s() - t0;
+  // the staged columns have done their work: release them before the gathered buffers are allocated
+  void* olds[] = {t->skey, t->ssid, t->soff};
+  for (void* p : olds)
+    if (p) SHZ_HIP(ctx, hipFree(p));
+  t->skey = t->ssid = t->soff = nullptr;
+  const uint64_t ns_local = t->ns;
+  t->ns = t->scap = 0;
+  // 2) exchange: every rank's run(s) into one buffer at the rank's displacement
+  uint64_t *ga = nullptr, *gb = nullptr;
+  struct guard { uint64_t** p[2]; ~guard() { for (auto q : p) if (*q) (void)hipFree(*q); } } gd{{&ga, &gb}};
+  std::vector<uint64_t> run_off{0};
+  t0 = now_s();
+  if (c && nranks > 1) {
+    if (hipMalloc(&ga, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 8));
+    std::vector<uint64_t> bcnt(nranks), bdis(nranks);
+    for (int r = 0; r < nranks; ++r) { bcnt[r] = cnt[r] * 8; bdis[r] = displ[r] * 8; run_off.push_back(displ[r] + cnt[r]); }
+    SHZ_TRY(shz_comm_allgatherv_bytes(c, pa, ga, bcnt.data(), bdis.data()));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes_recv) *bytes_recv = (total - ns_local) * 8;
+  } else {
+    if (hipMalloc(&ga, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "hipMalloc(%llu) failed", (unsigned long long)(total * 8));
+    SHZ_HIP(ctx, hipMemcpyAsync(ga, pa, total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    uint64_t acc = 0;
+    for (uint64_t r : my_runs) { acc += r; run_off.push_back(acc); }
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  t->bs_exchange = now_s() - t0;
+  // 3) merge the runs
+  t0 = now_s();
+  uint64_t* g = ga;
+  if (run_off.size() > 2) {
+    if (hipMalloc(&gb, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "merge: hipMalloc(%llu) failed", (unsigned long long)(total * 8));
+    SHZ_TRY(merge_runs(ctx, ga, gb, run_off, &g));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t** other = (g == ga) ? &gb : &ga;   // the buffer that does not hold the result goes before the columns come
+    (void)hipFree(*other);
+    *other = nullptr;
+  }
+  t->bs_merge = now_s() - t0;
+  // 4) segments
+  t0 = now_s();
+  t->max_sid = std::max<uint32_t>(t->max_sid, (uint32_t)gmax_sid);
+  t->max_off = std::max<uint32_t>(t->max_off, (uint32_t)gmax_off);
+  SHZ_TRY(segments_from_sorted(t, g, total, sb, ob));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->bs_segments = now_s() - t0;
+  return SHZ_OK;
+}
+
+// the exchange of unsorted columns followed by one sort of everything: tables that already hold rows, or ids / offsets
+// too wide for the packed form
+static int32_t allgather_columns(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
+  shz_ctx* ctx = t->ctx;
   int rank, nranks;
   shz_comm_info(c, &rank, &nranks);
   // 1) exchange staged-row counts
@@ -971,15 +1178,48 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
   dev_cols gc;
   if (!gc.alloc(total)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 4));
   const uint32_t* mine_cols[3] = {t->skey, t->ssid, t->soff};
+  const double t0 = now_s();
   for (int i = 0; i < 3; ++i) SHZ_TRY(shz_comm_allgatherv_bytes(c, mine_cols[i], gc.p[i], bytes.data(), displ.data()));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->bs_sort = t->bs_merge = 0.0;
+  t->bs_exchange = now_s() - t0;
   // 3) the gathered columns become the staged rows; finalize sorts + dedups them with the existing table
   void* olds[] = {t->skey, t->ssid, t->soff};
   for (void* p : olds)
     if (p) SHZ_HIP(ctx, hipFree(p));
   t->skey = gc.take(0); t->ssid = gc.take(1); t->soff = gc.take(2);
   t->ns = t->scap = total;
-  return shz_table_finalize(t);
+  const double t1 = now_s();
+  const int32_t rc = shz_table_finalize(t);
+  t->bs_segments = now_s() - t1;
+  return rc;
+}
+
+extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
+  if (!t || !c) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  const int32_t rc = build_from_runs(t, c, nullptr, 0, bytes_recv);
+  return rc == SHZ_I_GENERAL_PATH ? allgather_columns(t, c, bytes_recv) : rc;
+}
+
+extern "C" int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_rows, uint32_t n_runs) {
+  if (!t || (n_runs && !run_rows)) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  const int32_t rc = build_from_runs(t, nullptr, run_rows, n_runs, nullptr);
+  return rc == SHZ_I_GENERAL_PATH ? shz_table_finalize(t) : rc;   // not an empty table / ids too wide
+}
+
+extern "C" int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, double* merge_s, double* segments_s) {
+  if (!t) return SHZ_E_INVALID;
+  if (sort_s) *sort_s = t->bs_sort;
+  if (exchange_s) *exchange_s = t->bs_exchange;
+  if (merge_s) *merge_s = t->bs_merge;
+  if (segments_s) *segments_s = t->bs_segments;
+  return SHZ_OK;
 }
 
 // ======================================================================================== match

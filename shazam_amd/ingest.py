@@ -37,6 +37,49 @@ def merge_rows(parts):
     return rows[:, 0].astype(np.uint32), rows[:, 1].astype(np.uint32), rows[:, 2].astype(np.uint32)
 
 
+def pack_rows(key32, sid, off, sid_bits: int, off_bits: int) -> np.ndarray:
+    """key << (sid_bits + off_bits) | sid << off_bits | off: the 8-byte form in which rows are sorted, travel between
+    the ranks and are merged (csrc/shz_table.hip: tbl_compose1_kernel); its numeric order is the table's order."""
+    return ((np.asarray(key32, np.uint64) << np.uint64(sid_bits + off_bits)) | (np.asarray(sid, np.uint64) << np.uint64(off_bits))
+            | np.asarray(off, np.uint64))
+
+
+def merge_sorted_runs(runs, sid_bits: int, off_bits: int, segment_rows: int = 1 << 31):
+    """Host-side statement of what shz_table_allgather does with the ranks' SORTED packed runs: pairwise
+    merges until one run is left, duplicates dropped, the run cut into segments of <= segment_rows input rows.
+    Returns a list of (key32, sid, off) segments."""
+    runs = [np.asarray(r, np.uint64) for r in runs]
+    for r in runs:
+        assert np.all(r[1:] >= r[:-1]), "every rank sorts its own rows before the exchange"
+    while len(runs) > 1:
+        nxt = []
+        for i in range(0, len(runs), 2):
+            if i + 1 == len(runs):
+                nxt.append(runs[i])
+            else:   # merge of two sorted runs, ties keep the left run's element first (tbl_merge_kernel)
+                a, b = runs[i], runs[i + 1]
+                out = np.empty(len(a) + len(b), np.uint64)
+                ia = np.searchsorted(b, a, side="left") + np.arange(len(a))    # elements of b strictly below a[i]
+                ib = np.searchsorted(a, b, side="right") + np.arange(len(b))   # elements of a at or below b[j]
+                out[ia], out[ib] = a, b
+                nxt.append(out)
+        runs = nxt
+    g = runs[0] if runs else np.zeros(0, np.uint64)
+    segs = []
+    m_s, m_o = np.uint64((1 << sid_bits) - 1), np.uint64((1 << off_bits) - 1)
+    for o in range(0, len(g), segment_rows):
+        c = g[o:o + segment_rows]
+        keep = np.ones(len(c), bool)
+        keep[1:] = c[1:] != c[:-1]
+        if o > 0:
+            keep[0] = c[0] != g[o - 1]
+        c = c[keep]
+        if len(c):
+            segs.append(((c >> np.uint64(sid_bits + off_bits)).astype(np.uint32), ((c >> np.uint64(off_bits)) & m_s).astype(np.uint32),
+                         (c & m_o).astype(np.uint32)))
+    return segs
+
+
 class ShardedBuilder:
     """Fingerprints this rank's block of tracks on its GPU and builds the node-global table.
 

@@ -9,7 +9,7 @@ import socket
 import numpy as np
 import pytest
 
-from shazam_amd.ingest import merge_rows, shard_tracks, song_id_of_track
+from shazam_amd.ingest import merge_rows, merge_sorted_runs, pack_rows, shard_tracks, song_id_of_track
 
 N_TRACKS = 7
 
@@ -37,7 +37,16 @@ def _worker(rank, world, port, q):
     parts = [None] * world
     dist.all_gather_object(parts, mine)
     k, s, o = merge_rows(parts)
-    q.put((rank, lo, hi, k, s, o))
+    # the path shz_table_allgather takes into an empty table: maxima agreed first, every rank sorts its own rows packed,
+    # the sorted runs travel, every rank merges them and cuts segments (small segments here to cross a cut)
+    mx = [None] * world
+    dist.all_gather_object(mx, (int(mine[1].max(initial=0)), int(mine[2].max(initial=0))))
+    sb, ob = max(a for a, _ in mx).bit_length() or 1, max(b for _, b in mx).bit_length() or 1
+    run = np.sort(pack_rows(*mine, sb, ob))
+    runs = [None] * world
+    dist.all_gather_object(runs, run)
+    segs = merge_sorted_runs(runs, sb, ob, segment_rows=5000)
+    q.put((rank, lo, hi, k, s, o, segs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +78,10 @@ def test_two_rank_build_equals_single_rank():
         assert p.exitcode == 0
     want = merge_rows([_rows_of_tracks(0, N_TRACKS)])
     assert sorted((g[1], g[2]) for g in got) == [(0, 4), (4, 7)]
-    for _, _, _, k, s, o in got:   # every rank ends with the same, complete table
+    for _, _, _, k, s, o, segs in got:   # every rank ends with the same, complete table
         assert np.array_equal(k, want[0]) and np.array_equal(s, want[1]) and np.array_equal(o, want[2])
+        # ... and so does the sorted-run merge: its segments, concatenated, are that table (rows unique across the cuts)
+        assert len(segs) > 1
+        for col in range(3):
+            assert np.array_equal(np.concatenate([sg[col] for sg in segs]), want[col])
     assert set(np.unique(want[1]).tolist()) == set(range(1, N_TRACKS + 1))
