@@ -34,6 +34,23 @@ int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out) {
   return SHZ_OK;
 }
 
+int32_t shz_mailbox(shz_ctx* ctx, uint64_t bytes, void** out) {
+  if (ctx->mail_cap < bytes) {
+    if (ctx->mail) {
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      SHZ_HIP(ctx, hipHostFree(ctx->mail));
+      ctx->mail = nullptr;
+      ctx->mail_cap = 0;
+    }
+    const uint64_t want = std::max<uint64_t>(bytes + bytes / 2, 1ull << 16);
+    if (hipHostMalloc(&ctx->mail, want, hipHostMallocDefault) != hipSuccess)
+      SHZ_FAIL(ctx, SHZ_E_NOMEM, "hipHostMalloc(%llu) failed", (unsigned long long)want);
+    ctx->mail_cap = want;
+  }
+  *out = ctx->mail;
+  return SHZ_OK;
+}
+
 #define SHZ_PIN_CHUNK (8ull << 20)
 
 hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, hipMemcpyKind kind) {
@@ -147,6 +164,7 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
   if (ctx->d_window) (void)hipFree(ctx->d_window);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
+  if (ctx->mail) (void)hipHostFree(ctx->mail);
   for (int i = 0; i < 2; ++i) {
     if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
     if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);

@@ -99,6 +99,8 @@ struct shz_ctx {
   void* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
+  void* mail = nullptr;         // shz_mailbox
+  uint64_t mail_cap = 0;
 };
 
 // Copy on ctx->stream.  Host <-> device copies of 16 KB .. 64 MB go through pinned bounce buffers owned by the context
@@ -108,6 +110,10 @@ struct shz_ctx {
 // copies use the runtime's own staging, larger ones amortise one such event.  H2D: the source may be reused on return;
 // D2H (bounced sizes): the data is there on return.
 hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, hipMemcpyKind kind);
+
+// pinned host memory owned by the ctx for small latency-critical transfers (counts, result blocks, query uploads):
+// grows to the largest request; contents are the caller's between two calls
+int32_t shz_mailbox(shz_ctx* ctx, uint64_t bytes, void** out);
 
 // ensure ws slot has >= bytes (grow-only; contents not preserved)
 int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out);

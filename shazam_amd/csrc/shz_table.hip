@@ -1266,6 +1266,29 @@ __global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint3
   c[i] = ((uint64_t)lo << QIDX_SHIFT) | ((uint64_t)key32[h] << QKEY_SHIFT) | (o & ((1u << QOFF_BITS) - 1));
 }
 
+// Counts that used to travel to the host between the stages (unique elements, groups) stay on the device: kernels
+// are launched over a host-known bound and read the count here.  mctl sits in the first 256 bytes of SHZ_WS_MISC0.
+struct mctl {
+  unsigned long long mu;      // unique (query, key, offset) elements
+  unsigned long long ng;      // groups = distinct (query, key)
+  unsigned long long rows;    // table rows under the probed keys
+  unsigned long long P;       // votes
+  unsigned long long G;       // (query, song) groups of the votes
+  unsigned long long pad[3];
+  unsigned int err[4];        // [0] offset too wide, [1] largest query offset, [2] hashes this shard owns
+};
+// the filler element that stands for the hashes other shards own sorts last: it is not an element
+__global__ void m_fix_mu_kernel(mctl* c, unsigned long long m) {
+  if (c->err[2] < m && c->mu) --c->mu;
+}
+// flag[i] = 1 where (c[i] >> shift) differs from its predecessor, for i < *n (0 beyond, up to the launch bound)
+__global__ void m_head_flag_dn_kernel(const uint64_t* __restrict__ c, const unsigned long long* __restrict__ n,
+                                      uint64_t bound, int shift, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bound) return;
+  flag[i] = (i < *n && (i == 0 || (c[i] >> shift) != (c[i - 1] >> shift))) ? 1u : 0u;
+}
+
 // flag[i] = 1 where (c[i] >> shift) differs from its predecessor
 __global__ void m_head_flag_kernel(const uint64_t* __restrict__ c, uint64_t n, int shift, uint32_t* __restrict__ flag) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1280,21 +1303,24 @@ __global__ void m_compact_vals_kernel(const uint64_t* __restrict__ c, const uint
 }
 
 // starts[pos[i]] = i for heads; starts[n_heads] = n
-__global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n,
-                                     const uint64_t* __restrict__ n_heads, uint32_t* __restrict__ starts) {
+__global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos,
+                                     const unsigned long long* __restrict__ n_dev, uint64_t bound,
+                                     const unsigned long long* __restrict__ n_heads, uint32_t* __restrict__ starts) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t n = *n_dev;
   if (i == 0) starts[*n_heads] = (uint32_t)n;
-  if (i < n && flag[i]) starts[pos[i]] = (uint32_t)i;
+  if (i < bound && i < n && flag[i]) starts[pos[i]] = (uint32_t)i;
 }
 
 // probe: rows [lo, lo+rows) of every (query, key) group g in every segment sg, one thread per x = g * nseg + sg.
 // g_lo[x] = first row, g_pairs[x] = rows x offsets of the group (the votes it expands to); x = ng * nseg is the
 // sentinel that makes the exclusive scan end in the total.
-__global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs, uint32_t ng,
+__global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                               const unsigned long long* __restrict__ ng_dev, uint64_t bound,
                                const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint32_t* __restrict__ g_lo,
                                uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total) {
   const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t nx = (uint64_t)ng * nseg;
+  const uint64_t nx = (uint64_t)*ng_dev * nseg;   // <= bound - 1: slots past nx count no pairs
   unsigned long long s = 0;
   if (x < nx) {
     const uint32_t g = (uint32_t)(x / nseg), sg = (uint32_t)(x - (uint64_t)g * nseg);
@@ -1321,7 +1347,7 @@ __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* _
     g_lo[x] = lo;
     g_pairs[x] = (uint64_t)rows * (gs[g + 1] - e0);
     s = rows;
-  } else if (x == nx) {
+  } else if (x < bound) {
     g_pairs[x] = 0;
   }
 #pragma unroll
@@ -1707,11 +1733,12 @@ __global__ __launch_bounds__(256) void m_reduce_long_kernel(const uint64_t* __re
 }
 
 // group records [r0, r1) of query q: qstart[] holds the first record of every query that has any (0xFFFFFFFF = none)
-__device__ __forceinline__ void m_query_groups(const uint32_t* __restrict__ qstart, uint32_t nq, uint32_t G, uint32_t q,
-                                               uint32_t& r0, uint32_t& r1) {
+__device__ __forceinline__ void m_query_groups(const uint32_t* __restrict__ qstart, uint32_t nq,
+                                               const unsigned long long* __restrict__ G, uint32_t q, uint32_t& r0,
+                                               uint32_t& r1) {
   r0 = qstart[q];
   if (r0 == 0xFFFFFFFFu) { r0 = r1 = 0; return; }
-  r1 = G;
+  r1 = (uint32_t)*G;
   for (uint32_t k = q + 1; k < nq; ++k) {
     const uint32_t x = qstart[k];
     if (x != 0xFFFFFFFFu) { r1 = x; break; }
@@ -1719,7 +1746,8 @@ __device__ __forceinline__ void m_query_groups(const uint32_t* __restrict__ qsta
 }
 
 // one workgroup per query: top-n groups by (count desc, sid asc) over the packed group summaries
-__global__ __launch_bounds__(256) void m_topn_kernel(const uint32_t* __restrict__ qstart, uint32_t G, m_bits mb,
+__global__ __launch_bounds__(256) void m_topn_kernel(const uint32_t* __restrict__ qstart,
+                                                     const unsigned long long* __restrict__ G, m_bits mb,
                                                      const uint64_t* __restrict__ g_pack,
                                                      const uint32_t* __restrict__ g_delta,
                                                      const uint32_t* __restrict__ g_dedup, uint32_t nq, uint32_t topn,
@@ -1791,7 +1819,8 @@ __device__ __forceinline__ void topn_block_max(uint64_t& best, uint32_t& bestr, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void m_topn_partial_kernel(const uint32_t* __restrict__ qstart, uint32_t G, uint32_t nq,
+__global__ __launch_bounds__(256) void m_topn_partial_kernel(const uint32_t* __restrict__ qstart,
+                                                             const unsigned long long* __restrict__ G, uint32_t nq,
                                                              const uint64_t* __restrict__ g_pack, uint32_t topn, uint64_t* __restrict__ part_pack,
                                                              uint32_t* __restrict__ part_r) {
   __shared__ uint64_t s_best[4];
@@ -1884,31 +1913,31 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
   uint2* long_list = (uint2*)(long_cnt + 1 + ((nw * 2 + nq + 1) & 1));   // 8-byte aligned behind the counter
   hipLaunchKernelGGL(m_gcount_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb.dbits + 1, wcnt);
   SHZ_HIP(ctx, hipGetLastError());
-  SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));
-  uint64_t G64 = 0;
-  SHZ_HIP(ctx, shz_memcpy(ctx, &G64, d_tot, 8, hipMemcpyDeviceToHost));
+  SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));   // *d_tot = G, the number of (query, song) groups: stays on the device
   SHZ_HIP(ctx, hipMemsetAsync(qstart, 0xFF, (uint64_t)nq * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(long_cnt, 0, 4, ctx->stream));
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t G = (uint32_t)G64;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, (uint64_t)G * 8, &gh));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, (uint64_t)G * 4, &gd));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (uint64_t)G * 4, &gdd));
+  // G <= P, and a group needs a vote per song: the record arrays are sized by that bound instead of a read-back of G
+  const uint64_t Gb = P;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, Gb * 8, &gh));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, Gb * 4, &gd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, Gb * 4, &gdd));
+  const unsigned long long* d_G = (const unsigned long long*)d_tot;
   hipLaunchKernelGGL(m_reduce_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb, (const uint32_t*)wbase, (uint64_t*)gh,
                      (uint32_t*)gd, (uint32_t*)gdd, qstart, long_cnt, long_list);
   hipLaunchKernelGGL(m_reduce_long_kernel, dim3(std::min<uint32_t>(1024, nb)), dim3(256), 0, ctx->stream, vs, P, mb,
                      (const uint32_t*)long_cnt, (const uint2*)long_list, (uint64_t*)gh, (uint32_t*)gd, (uint32_t*)gdd);
-  // groups per query decide the shape: one workgroup per query, or C slices per query and a final ranking
-  const uint32_t C = (uint32_t)std::min<uint64_t>(512, ((uint64_t)G / nq + 16383) / 16384);
+  // groups per query decide the shape: one workgroup per query, or C slices per query and a final ranking.  The bound
+  // votes / queries stands in for groups / queries (more slices than needed cost a few idle workgroups).
+  const uint32_t C = (uint32_t)std::min<uint64_t>(512, (P / nq + 16383) / 16384);
   if (C <= 1) {
-    hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, G, mb, (const uint64_t*)gh,
+    hipLaunchKernelGGL(m_topn_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, d_G, mb, (const uint64_t*)gh,
                        (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
   } else {
     void *pp, *pr;
     const uint64_t ncand = (uint64_t)C * topn;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)nq * ncand * 8, &pp));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nq * ncand * 4, &pr));
-    hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, G, nq,
+    hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, d_G, nq,
                        (const uint64_t*)gh, topn, (uint64_t*)pp, (uint32_t*)pr);
     hipLaunchKernelGGL(m_topn_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint64_t*)pp, (const uint32_t*)pr,
                        (uint32_t)ncand, mb, (const uint32_t*)gd, (const uint32_t*)gdd, nq, topn, r_sid, r_delta, r_al, r_dd, r_n);
@@ -1937,24 +1966,48 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   for (const shz_seg& g : all_segs(t)) hsegs.push_back(shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets});
   if (hsegs.empty()) hsegs.push_back(shz_seg_dev{nullptr, nullptr, nullptr, t->bucket, 0u, 0ull});
   const int nseg = (int)hsegs.size();
-  void* d_segs;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, sizeof(shz_seg_dev) * SHZ_MAX_SEGS, &d_segs));
-  SHZ_HIP(ctx, shz_memcpy(ctx, d_segs, hsegs.data(), sizeof(shz_seg_dev) * nseg, hipMemcpyHostToDevice));
   m_bits mb;
   mb.sb = bits_for(t->max_sid);
   mb.dbits = 0;
   mb.bias = 0;
-  // whole query set on the device once
+  // the query set on the device once.  Host input of moderate size travels as ONE copy from pinned memory:
+  // segment descriptors | query offsets | keys | offsets (every separate small copy costs ~20 us of latency)
   const uint64_t h0 = query_off[0], h1 = query_off[n_queries];
   const uint32_t *d_key = key32, *d_qo = q_off;
-  if (!(flags & SHZ_IN_DEVICE) && h1 > 0) {
-    void *a, *b;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, h1 * 4, &a));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, h1 * 4, &b));
-    SHZ_HIP(ctx, shz_memcpy(ctx, a, key32, h1 * 4, hipMemcpyHostToDevice));
-    SHZ_HIP(ctx, shz_memcpy(ctx, b, q_off, h1 * 4, hipMemcpyHostToDevice));
-    d_key = (const uint32_t*)a;
-    d_qo = (const uint32_t*)b;
+  void* d_segs;
+  const uint64_t* d_qoff_all = nullptr;   // query_off[0 .. n_queries] on the device, when it went with the packed upload
+  const uint64_t seg_bytes = (sizeof(shz_seg_dev) * (uint64_t)nseg + 255) & ~255ull;
+  const uint64_t qoff_bytes = (((uint64_t)n_queries + 1) * 8 + 255) & ~255ull;
+  const uint64_t pk_bytes = seg_bytes + qoff_bytes + ((h1 * 4 + 255) & ~255ull) * 2;
+  if (!(flags & SHZ_IN_DEVICE) && pk_bytes <= (4ull << 20)) {
+    void *hm, *dm;
+    SHZ_TRY(shz_mailbox(ctx, pk_bytes, &hm));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, pk_bytes, &dm));
+    char* hp = (char*)hm;
+    memcpy(hp, hsegs.data(), sizeof(shz_seg_dev) * nseg);
+    memcpy(hp + seg_bytes, query_off, ((uint64_t)n_queries + 1) * 8);
+    const uint64_t ko = seg_bytes + qoff_bytes, oo = ko + ((h1 * 4 + 255) & ~255ull);
+    if (h1) {
+      memcpy(hp + ko, key32, h1 * 4);
+      memcpy(hp + oo, q_off, h1 * 4);
+    }
+    SHZ_HIP(ctx, hipMemcpyAsync(dm, hm, pk_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_segs = dm;
+    d_qoff_all = (const uint64_t*)((char*)dm + seg_bytes);
+    d_key = (const uint32_t*)((char*)dm + ko);
+    d_qo = (const uint32_t*)((char*)dm + oo);
+  } else {
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, sizeof(shz_seg_dev) * SHZ_MAX_SEGS, &d_segs));
+    SHZ_HIP(ctx, shz_memcpy(ctx, d_segs, hsegs.data(), sizeof(shz_seg_dev) * nseg, hipMemcpyHostToDevice));
+    if (!(flags & SHZ_IN_DEVICE) && h1 > 0) {
+      void *a, *b;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, h1 * 4, &a));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, h1 * 4, &b));
+      SHZ_HIP(ctx, shz_memcpy(ctx, a, key32, h1 * 4, hipMemcpyHostToDevice));
+      SHZ_HIP(ctx, shz_memcpy(ctx, b, q_off, h1 * 4, hipMemcpyHostToDevice));
+      d_key = (const uint32_t*)a;
+      d_qo = (const uint32_t*)b;
+    }
   }
   (void)h0;
   uint32_t q0 = 0;
@@ -1966,12 +2019,18 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint64_t m = query_off[q0 + nq] - query_off[q0];
     if (m >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u has too many hashes", q0);
     mb.qb = bits_for(nq - 1);
-    void *d_qoff, *c0, *c1, *fl, *ps, *tot, *err;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
-    SHZ_HIP(ctx, shz_memcpy(ctx, d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &tot));
-    err = (char*)tot + 128;
-    SHZ_HIP(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
+    void *d_qoff, *c0, *c1, *fl, *ps, *ctl_p;
+    if (d_qoff_all) {
+      d_qoff = (void*)(d_qoff_all + q0);
+    } else {
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
+      SHZ_HIP(ctx, shz_memcpy(ctx, d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice));
+    }
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &ctl_p));
+    mctl* d_ctl = (mctl*)ctl_p;
+    uint64_t* tot = (uint64_t*)ctl_p;      // tot[0..4] = mu, ng, rows, P, G
+    uint32_t* err = d_ctl->err;
+    SHZ_HIP(ctx, hipMemsetAsync(ctl_p, 0, 256, ctx->stream));
     if (m == 0) {
       for (uint32_t q = 0; q < nq; ++q) {
         if (out_nres) out_nres[q0 + q] = 0;
@@ -1981,11 +2040,16 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       q0 += nq;
       continue;
     }
+    const uint64_t nx_bound = m * (uint64_t)nseg + 1;   // sub-groups (group x segment) + sentinel, from the bound groups <= m
+    if (nx_bound >= (1ull << 32)) {
+      if (nq > 1) { step = nq / 2; continue; }
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u: %llu hashes x %d segments", q0, (unsigned long long)m, nseg);
+    }
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, m * 8, &c0));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, m * 8, &c1));
     const uint32_t f_nsh = vs_out ? vs_out->nshards : 1u, f_sh = vs_out ? vs_out->shard : 0u;
     hipLaunchKernelGGL(m_compose_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, d_key, d_qo, (const uint64_t*)d_qoff, nq,
-                       m, f_nsh, f_sh, (uint64_t*)c0, (uint32_t*)err);
+                       m, f_nsh, f_sh, (uint64_t*)c0, err);
     SHZ_HIP(ctx, hipGetLastError());
     int sel = 0;
     SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)c0, (uint64_t*)c1, nullptr, nullptr, 0, m, 0,
@@ -1994,19 +2058,36 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     uint64_t* E = sel ? (uint64_t*)c0 : (uint64_t*)c1;    // unique elements go to the other buffer
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, m * 4, &fl));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, m * 4, &ps));
-    // unique (query, key, off)
+    // unique (query, key, off): mu of them; groups = distinct (query, key): ng of them; probe; pairs -- queued without a
+    // host round trip in between: every launch is sized by the bound m, the counts are read on the device (mctl)
+    void *gs, *glo, *gpairs, *po;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (m + 1) * 4, &gs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, nx_bound * 4, &glo));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, nx_bound * 8, &gpairs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, nx_bound * 8, &po));
     hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs, m, 0, (uint32_t*)fl);
-    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, (uint64_t*)tot));
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, tot));
     hipLaunchKernelGGL(m_compact_vals_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs,
                        (const uint32_t*)fl, (const uint32_t*)ps, m, E);
+    hipLaunchKernelGGL(m_fix_mu_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, (unsigned long long)m);
+    hipLaunchKernelGGL(m_head_flag_dn_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)E, &d_ctl->mu, m,
+                       QKEY_SHIFT, (uint32_t*)fl);
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, tot + 1));
+    hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
+                       (const uint32_t*)ps, &d_ctl->mu, m, &d_ctl->ng, (uint32_t*)gs);
+    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx_bound)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                       (const uint32_t*)gs, &d_ctl->ng, nx_bound, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
+                       (uint64_t*)gpairs, &d_ctl->rows);
     SHZ_HIP(ctx, hipGetLastError());
-    uint64_t mu = 0;
-    uint32_t herr[3] = {0, 0, 0};
-    SHZ_HIP(ctx, shz_memcpy(ctx, &mu, tot, 8, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, shz_memcpy(ctx, herr, err, 12, hipMemcpyDeviceToHost));
+    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx_bound, tot + 3));
+    // the one read-back before the votes: their number sizes the vote buffers and the sort
+    void* mailp;
+    SHZ_TRY(shz_mailbox(ctx, sizeof(mctl), &mailp));
+    SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, sizeof(mctl), hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (herr[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
-    if (herr[2] < m) --mu;  // the filler element of the hashes other shards own sorts last: drop it
+    const mctl h = *(const mctl*)mailp;
+    if (h.err[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
+    const uint64_t mu = h.mu;
     if (mu == 0) {          // nothing of this sub-batch belongs to this shard
       for (uint32_t q = 0; q < nq; ++q) {
         if (out_nhash) out_nhash[q0 + q] = 0;
@@ -2015,45 +2096,19 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       q0 += nq;
       continue;
     }
-    mb.bias = herr[1];
+    mb.bias = h.err[1];
     mb.dbits = bits_for((uint64_t)t->max_off + mb.bias);
     if (vs_out) {  // the caller's layout must hold this table's ids and offsets and these queries' offsets
       const m_bits& L = vs_out->lay;
-      if (herr[1] > L.bias || bits_for(t->max_sid) > L.sb || bits_for((uint64_t)t->max_off + L.bias) > L.dbits)
+      if (h.err[1] > L.bias || bits_for(t->max_sid) > L.sb || bits_for((uint64_t)t->max_off + L.bias) > L.dbits)
         SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_match_pairs: layout (sid_bits %d, delta_bits %d, bias %u) too small for this table / these queries", L.sb, L.dbits, L.bias);
     } else if (mb.qb + mb.sb + mb.dbits + 1 > 64) {
       if (nq > 1) { step = nq / 2; continue; }
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song id / offset range too wide for the packed vote key");
     }
-    // groups = distinct (query, key)
-    void *gs, *glo, *gpairs, *po;
-    hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint64_t*)E, mu, QKEY_SHIFT,
-                       (uint32_t*)fl);
-    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, mu, (uint64_t*)tot + 1));
-    uint64_t ng64 = 0;
-    SHZ_HIP(ctx, shz_memcpy(ctx, &ng64, (uint64_t*)tot + 1, 8, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ng = (uint32_t)ng64;
+    const uint32_t ng = (uint32_t)h.ng;
     const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
-    if (nx >= (1ull << 32)) {
-      if (nq > 1) { step = nq / 2; continue; }
-      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u: %u distinct hashes x %d segments", q0, ng, nseg);
-    }
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)(ng + 1) * 4, &gs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (nx + 1) * 4, &glo));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, (nx + 1) * 8, &gpairs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, (nx + 1) * 8, &po));
-    hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(mu)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
-                       (const uint32_t*)ps, mu, (const uint64_t*)tot + 1, (uint32_t*)gs);
-    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
-                       (const uint32_t*)gs, ng, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
-                       (uint64_t*)gpairs, (unsigned long long*)tot + 2);
-    SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx + 1, (uint64_t*)tot + 3));
-    uint64_t P = 0, rows_total = 0;
-    SHZ_HIP(ctx, shz_memcpy(ctx, &P, (uint64_t*)tot + 3, 8, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, shz_memcpy(ctx, &rows_total, (uint64_t*)tot + 2, 8, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t P = h.P, rows_total = h.rows;
     if (P > P_BUDGET && nq > 1) {  // too many pairs for one pass: retry with fewer queries
       step = std::max<uint32_t>(1, nq / 2);
       continue;
@@ -2062,30 +2117,19 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     ctx->st_rows += rows_total;
     ctx->st_pairs += P;
     ctx->st_keys += ng;
-    // per-query counters
-    void *d_nh, *d_np;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)nq * 4, &d_nh));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)nq * 8, &d_np));
+    // results and per-query counters in ONE device block: one fill before, one copy after.
+    // layout: npairs[nq] u64 | sid, delta, aligned, dedup [nq * topn] u32 each | nres[nq] | nhash[nq]
+    const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
+    const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8;
+    void* rb;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
+    SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));
+    uint64_t* d_np = (uint64_t*)rb;
+    uint32_t* r_sid = (uint32_t*)(d_np + nq);
+    uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
     hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
-                       (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, (uint32_t*)d_nh, (uint64_t*)d_np);
+                       (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
     SHZ_HIP(ctx, hipGetLastError());
-    if (out_nhash) SHZ_HIP(ctx, shz_memcpy(ctx, out_nhash + q0, d_nh, (uint64_t)nq * 4, hipMemcpyDeviceToHost));
-    if (out_npairs) SHZ_HIP(ctx, shz_memcpy(ctx, out_npairs + q0, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost));
-    // device result buffers
-    void *r_sid = nullptr, *r_delta = nullptr, *r_al = nullptr, *r_dd = nullptr, *r_n = nullptr;
-    const uint64_t nres = (uint64_t)nq * topn;
-    if (!vs_out) {
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, nres * 4, &r_sid));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, nres * 4, &r_delta));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, nres * 4, &r_al));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, nres * 4, &r_dd));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, (uint64_t)nq * 4, &r_n));
-      SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
-      SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
-      SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
-      SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
-      SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)nq * 4, ctx->stream));
-    }
     const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
     void* tile_x = nullptr;
     if (P > 0 && (!vs_out || vs_out->count + P <= vs_out->cap)) {
@@ -2111,18 +2155,27 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                          (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
                          (uint32_t)nseg, P, mb, 0u, (uint64_t*)v0);
       SHZ_HIP(ctx, hipGetLastError());
-      SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, (uint64_t*)tot + 4, (uint32_t*)r_sid,
-                        (int32_t*)r_delta, (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
+      SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, tot + 4, r_sid, (int32_t*)r_delta, r_al, r_dd, r_n));
     }
-    if (!vs_out) {
-      const uint64_t o0 = (uint64_t)q0 * topn;
-      SHZ_HIP(ctx, shz_memcpy(ctx, out_sid + o0, r_sid, nres * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, shz_memcpy(ctx, out_delta + o0, r_delta, nres * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, shz_memcpy(ctx, out_aligned + o0, r_al, nres * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, shz_memcpy(ctx, out_dedup + o0, r_dd, nres * 4, hipMemcpyDeviceToHost));
-      SHZ_HIP(ctx, shz_memcpy(ctx, out_nres + q0, r_n, (uint64_t)nq * 4, hipMemcpyDeviceToHost));
+    {
+      void* hb;
+      SHZ_TRY(shz_mailbox(ctx, rb_bytes, &hb));
+      SHZ_HIP(ctx, hipMemcpyAsync(hb, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const uint64_t* h_np = (const uint64_t*)hb;
+      const uint32_t* h_sid = (const uint32_t*)(h_np + nq);
+      const uint32_t *h_delta = h_sid + nres, *h_al = h_delta + nres, *h_dd = h_al + nres, *h_n = h_dd + nres, *h_nh = h_n + nq;
+      if (out_npairs) memcpy(out_npairs + q0, h_np, (uint64_t)nq * 8);
+      if (out_nhash) memcpy(out_nhash + q0, h_nh, (uint64_t)nq * 4);
+      if (!vs_out) {
+        const uint64_t o0 = (uint64_t)q0 * topn;
+        memcpy(out_sid + o0, h_sid, nres * 4);
+        memcpy(out_delta + o0, h_delta, nres * 4);
+        memcpy(out_aligned + o0, h_al, nres * 4);
+        memcpy(out_dedup + o0, h_dd, nres * 4);
+        memcpy(out_nres + q0, h_n, (uint64_t)nq * 4);
+      }
     }
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     q0 += nq;
   }
   return SHZ_OK;
