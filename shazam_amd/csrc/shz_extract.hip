@@ -1275,17 +1275,37 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
       SHZ_HIP(ctx, hipGetLastError());
     }
   }
-  // the one read-back of the pass
-  SHZ_HIP(ctx, hipMemcpyAsync(hctl, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
-  if (offs_out) SHZ_HIP(ctx, shz_memcpy(ctx, offs_out, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost));
+  // The one read-back of the pass, into pinned memory: control block | per-clip offsets | for small host outputs the
+  // entries themselves (they ride along instead of costing a second round trip once the count is known).
+  const uint64_t b_a = want_hashes ? 4 : 2;
+  const uint64_t spec = (!out_dev && o_cap <= (1u << 15)) ? o_cap : 0;
+  const uint64_t off_offs = 256, off_a = off_offs + (((uint64_t)(n_clips + 1) * 8 + 255) & ~255ull);
+  const uint64_t off_b = off_a + ((spec * b_a + 255) & ~255ull), mail_bytes = off_b + spec * 4;
+  void* mailp;
+  SHZ_TRY(shz_mailbox(ctx, mail_bytes, &mailp));
+  char* mp = (char*)mailp;
+  SHZ_HIP(ctx, hipMemcpyAsync(mp, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
+  if (offs_out) SHZ_HIP(ctx, hipMemcpyAsync(mp + off_offs, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (spec) {
+    SHZ_HIP(ctx, hipMemcpyAsync(mp + off_a, o_a, spec * b_a, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(mp + off_b, o_b, spec * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(hctl, mp, sizeof(xctl));
+  if (offs_out) memcpy(offs_out, mp + off_offs, (uint64_t)(n_clips + 1) * 8);
   const uint64_t total = want_hashes ? hctl->hash_base : hctl->peak_base;
   const bool clean = !(hctl->flags & (XF_FALLBACK | XF_PEAK_CAP));
   if (clean && !out_dev && total <= cap && total <= o_cap && total) {
-    const uint64_t b_a = want_hashes ? 4 : 2;
-    SHZ_HIP(ctx, shz_memcpy(ctx, want_hashes ? (void*)key32 : (void*)peak_f, o_a, total * b_a, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, shz_memcpy(ctx, want_hashes ? (void*)t1 : (void*)peak_t, o_b, total * 4, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void* ha = want_hashes ? (void*)key32 : (void*)peak_f;
+    void* hb = want_hashes ? (void*)t1 : (void*)peak_t;
+    if (total <= spec) {
+      memcpy(ha, mp + off_a, total * b_a);
+      memcpy(hb, mp + off_b, total * 4);
+    } else {
+      SHZ_HIP(ctx, shz_memcpy(ctx, ha, o_a, total * b_a, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, shz_memcpy(ctx, hb, o_b, total * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
   return SHZ_OK;
 }

@@ -1289,6 +1289,213 @@ __global__ void m_head_flag_dn_kernel(const uint64_t* __restrict__ c, const unsi
   flag[i] = (i < *n && (i == 0 || (c[i] >> shift) != (c[i - 1] >> shift))) ? 1u : 0u;
 }
 
+// ---- head of the match for SMALL query sets (<= MH_MAX hashes, no shard filter) in ONE workgroup: compose, sort,
+// unique, group heads.  Replaces m_compose + the radix sort (1 to 21 launches) + 11 flag / scan / compact launches:
+// for one 5-10 s query the launches, not the work, were the latency.
+#define MH_THREADS 1024
+#define MH_ROWS 8
+#define MH_MAX (MH_THREADS * MH_ROWS)   // 8,192 elements: two 64 KB key buffers in LDS
+
+// exclusive scan of one value per thread over the 1024-thread workgroup; *total = sum.  tmp: >= 17 entries of LDS.
+__device__ __forceinline__ uint32_t mh_block_scan(uint32_t v, uint32_t* total, uint32_t* tmp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();   // tmp may still be read from the previous use
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MH_THREADS / 64; ++w) {
+    const uint32_t x = tmp[w];
+    if (w < wave) woff += x;
+    tot += x;
+  }
+  *total = tot;
+  return woff + inc - v;
+}
+
+// Stable LSD radix sort of m <= MH_MAX keys that sit in sk[0], on bits [bit_lo, bit_hi), 8 bits per pass, all in LDS.
+// Wave w owns the slice [w * 512, w * 512 + 512): every pass ranks a slice's elements among themselves by ballots
+// (the scheme of sort_scatter_kernel), prefixes the per-wave digit counts over the waves and the digits, and scatters
+// into the other buffer.  Passes over digits on which no two keys differ (`diff` = OR of all keys ^ AND of all keys)
+// are skipped.  Returns the index of the buffer that holds the result.  Ends with a barrier.
+__device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wrun)[256], uint32_t* dbase, uint32_t m,
+                                           int bit_lo, int bit_hi, unsigned long long diff) {
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cur = 0;
+  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    const uint32_t dmask = (1u << min(8, bit_hi - shift)) - 1u;
+    if (((diff >> shift) & dmask) == 0) continue;   // uniform
+    for (int i = j; i < (MH_THREADS / 64) * 256; i += MH_THREADS) (&wrun[0][0])[i] = 0;
+    __syncthreads();
+    uint64_t k[MH_ROWS];
+    uint32_t rank[MH_ROWS];
+#pragma unroll
+    for (int r = 0; r < MH_ROWS; ++r) {
+      const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+      const bool valid = li < m;
+      k[r] = valid ? sk[cur][li] : 0;
+      const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long mm = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? mm : ~mm;
+      }
+      const uint32_t rk = (uint32_t)__popcll(peers & lt);
+      const uint32_t run = wrun[wave][d];
+      rank[r] = run + rk;
+      if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    if (j < 256) {   // per digit: exclusive prefix over the waves, total of the digit
+      uint32_t acc = 0;
+#pragma unroll
+      for (int w = 0; w < MH_THREADS / 64; ++w) {
+        const uint32_t c = wrun[w][j];
+        wrun[w][j] = (uint16_t)acc;
+        acc += c;
+      }
+      dbase[j] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the 256 digit totals: 4 per lane
+      uint32_t a0 = dbase[4 * lane], a1 = dbase[4 * lane + 1], a2 = dbase[4 * lane + 2], a3 = dbase[4 * lane + 3];
+      uint32_t sum = a0 + a1 + a2 + a3, inc = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      uint32_t ex = inc - sum;
+      dbase[4 * lane] = ex; ex += a0;
+      dbase[4 * lane + 1] = ex; ex += a1;
+      dbase[4 * lane + 2] = ex; ex += a2;
+      dbase[4 * lane + 3] = ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MH_ROWS; ++r) {
+      const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+      if (li < m) {
+        const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
+        sk[cur ^ 1][dbase[d] + wrun[wave][d] + rank[r]] = k[r];
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  return cur;
+}
+
+// the votes of a small match (<= MH_MAX of them) sorted in one workgroup instead of 3-4 passes x 3 launches
+__global__ __launch_bounds__(MH_THREADS) void m_sort_small_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                  uint32_t n, int bit_lo, int bit_hi) {
+  __shared__ uint64_t sk[2][MH_MAX];
+  __shared__ uint16_t wrun[MH_THREADS / 64][256];
+  __shared__ uint32_t dbase[256];
+  for (uint32_t i = threadIdx.x; i < n; i += MH_THREADS) sk[0][i] = in[i];
+  __syncthreads();
+  const int cur = mh_lds_sort(sk, wrun, dbase, n, bit_lo, bit_hi, ~0ull);
+  for (uint32_t i = threadIdx.x; i < n; i += MH_THREADS) out[i] = sk[cur][i];
+}
+
+__global__ __launch_bounds__(MH_THREADS) void m_head_small_kernel(const uint32_t* __restrict__ key32,
+                                                                  const uint32_t* __restrict__ q_off,
+                                                                  const uint64_t* __restrict__ query_off, uint32_t nq,
+                                                                  uint32_t m, int bit_hi, uint64_t* __restrict__ E,
+                                                                  uint32_t* __restrict__ gs, mctl* __restrict__ ctl) {
+  __shared__ uint64_t sk[2][MH_MAX];
+  __shared__ uint16_t wrun[MH_THREADS / 64][256];
+  __shared__ uint32_t dbase[256], tmp[20];
+  __shared__ unsigned long long s_or, s_and;
+  __shared__ uint32_t s_omax;
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  if (j == 0) { s_or = 0; s_and = ~0ull; s_omax = 0; }
+  __syncthreads();
+  // compose (query, key, offset) elements; wave w owns the slice [w * 512, w * 512 + 512)
+  const uint64_t h0 = query_off[0];
+  unsigned long long vor = 0, vand = ~0ull;
+  uint32_t omax = 0;
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+    if (li < m) {
+      const uint64_t h = h0 + li;
+      const uint32_t o = q_off[h];
+      uint32_t lo = 0, hi = nq;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (query_off[mid] <= h) lo = mid; else hi = mid;
+      }
+      const uint64_t c = ((uint64_t)lo << QIDX_SHIFT) | ((uint64_t)key32[h] << QKEY_SHIFT) | (o & ((1u << QOFF_BITS) - 1));
+      sk[0][li] = c;
+      vor |= c;
+      vand &= c;
+      omax = max(omax, o);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    vor |= __shfl_xor((long long)vor, d, 64);
+    vand &= __shfl_xor((long long)vand, d, 64);
+    omax = max(omax, (uint32_t)__shfl_xor((int)omax, d, 64));
+  }
+  if (lane == 0) {
+    atomicOr(&s_or, vor);
+    atomicAnd(&s_and, vand);
+    atomicMax(&s_omax, omax);
+  }
+  __syncthreads();
+  const unsigned long long diff = s_or ^ s_and;   // bits on which the elements differ at all: other digits need no pass
+  const int cur = mh_lds_sort(sk, wrun, dbase, m, 0, bit_hi, diff);
+  // unique elements: thread j looks at the MH_ROWS consecutive sorted elements [j * 8, j * 8 + 8)
+  const uint64_t* S = sk[cur];
+  uint64_t* U = sk[cur ^ 1];
+  uint32_t f = 0, cnt = 0;
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r) {
+    const uint32_t i = (uint32_t)j * MH_ROWS + r;
+    if (i < m && (i == 0 || S[i] != S[i - 1])) { f |= 1u << r; ++cnt; }
+  }
+  uint32_t mu;
+  uint32_t pos = mh_block_scan(cnt, &mu, tmp);
+  uint64_t mine[MH_ROWS];
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r) mine[r] = S[(uint32_t)j * MH_ROWS + r];
+  __syncthreads();   // everybody has read S before U (the other buffer) is written; U != S, but keep the phases apart
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r)
+    if ((f >> r) & 1u) { U[pos] = mine[r]; E[pos] = mine[r]; ++pos; }
+  __syncthreads();
+  // group heads: first element of every distinct (query, key)
+  f = 0; cnt = 0;
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r) {
+    const uint32_t i = (uint32_t)j * MH_ROWS + r;
+    if (i < mu && (i == 0 || (U[i] >> QKEY_SHIFT) != (U[i - 1] >> QKEY_SHIFT))) { f |= 1u << r; ++cnt; }
+  }
+  uint32_t ng;
+  pos = mh_block_scan(cnt, &ng, tmp);
+#pragma unroll
+  for (int r = 0; r < MH_ROWS; ++r)
+    if ((f >> r) & 1u) gs[pos++] = (uint32_t)j * MH_ROWS + r;
+  if (j == 0) {
+    gs[ng] = mu;
+    ctl->mu = mu;
+    ctl->ng = ng;
+    ctl->err[0] = (s_omax >> QOFF_BITS) ? 1u : 0u;
+    ctl->err[1] = s_omax;
+    ctl->err[2] = m;
+  }
+}
+
 // flag[i] = 1 where (c[i] >> shift) differs from its predecessor
 __global__ void m_head_flag_kernel(const uint64_t* __restrict__ c, uint64_t n, int shift, uint32_t* __restrict__ flag) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1902,7 +2109,14 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
                          uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
   int sel = 0;
   // bit 0 (the first-offset flag) is only counted by the fold, never compared: it stays out of the sort
-  SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
+  if (P <= MH_MAX) {
+    hipLaunchKernelGGL(m_sort_small_kernel, dim3(1), dim3(MH_THREADS), 0, ctx->stream, (const uint64_t*)v0, v1, (uint32_t)P, 1,
+                       mb.qb + mb.sb + mb.dbits + 1);
+    SHZ_HIP(ctx, hipGetLastError());
+    sel = 1;
+  } else {
+    SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
+  }
   const uint64_t* vs = sel ? v1 : v0;
   // group heads per wave -> first record slot of every wave -> one record per (query, sid) group
   const uint32_t nb = nblk((P + RG_PER - 1) / RG_PER), nw = nb * 4;
@@ -2019,6 +2233,9 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint64_t m = query_off[q0 + nq] - query_off[q0];
     if (m >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u has too many hashes", q0);
     mb.qb = bits_for(nq - 1);
+    static const bool trace = [] { const char* e = getenv("SHZ_TRACE_MATCH"); return e && atoi(e) != 0; }();
+    const double tr0 = trace ? now_s() : 0.0;
+    double tr1 = 0, tr2 = 0, tr3 = 0;
     void *d_qoff, *c0, *c1, *fl, *ps, *ctl_p;
     if (d_qoff_all) {
       d_qoff = (void*)(d_qoff_all + q0);
@@ -2048,6 +2265,19 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, m * 8, &c0));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, m * 8, &c1));
     const uint32_t f_nsh = vs_out ? vs_out->nshards : 1u, f_sh = vs_out ? vs_out->shard : 0u;
+    void *gs, *glo, *gpairs, *po;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (m + 1) * 4, &gs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, nx_bound * 4, &glo));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, nx_bound * 8, &gpairs));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, nx_bound * 8, &po));
+    uint64_t* E;
+    static const bool no_small_head = [] { const char* e = getenv("SHZ_MATCH_NO_SMALL_HEAD"); return e && atoi(e) != 0; }();
+    if (f_nsh == 1 && m <= MH_MAX && !no_small_head) {
+      E = (uint64_t*)c1;
+      hipLaunchKernelGGL(m_head_small_kernel, dim3(1), dim3(MH_THREADS), 0, ctx->stream, d_key, d_qo, (const uint64_t*)d_qoff,
+                         nq, (uint32_t)m, QIDX_SHIFT + mb.qb, E, (uint32_t*)gs, d_ctl);
+      SHZ_HIP(ctx, hipGetLastError());
+    } else {
     hipLaunchKernelGGL(m_compose_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, d_key, d_qo, (const uint64_t*)d_qoff, nq,
                        m, f_nsh, f_sh, (uint64_t*)c0, err);
     SHZ_HIP(ctx, hipGetLastError());
@@ -2055,16 +2285,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)c0, (uint64_t*)c1, nullptr, nullptr, 0, m, 0,
                          QIDX_SHIFT + (f_nsh > 1 ? bits_for(nq) : mb.qb), &sel));
     uint64_t* cs = sel ? (uint64_t*)c1 : (uint64_t*)c0;   // sorted
-    uint64_t* E = sel ? (uint64_t*)c0 : (uint64_t*)c1;    // unique elements go to the other buffer
+    E = sel ? (uint64_t*)c0 : (uint64_t*)c1;              // unique elements go to the other buffer
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, m * 4, &fl));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, m * 4, &ps));
     // unique (query, key, off): mu of them; groups = distinct (query, key): ng of them; probe; pairs -- queued without a
     // host round trip in between: every launch is sized by the bound m, the counts are read on the device (mctl)
-    void *gs, *glo, *gpairs, *po;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (m + 1) * 4, &gs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, nx_bound * 4, &glo));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, nx_bound * 8, &gpairs));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M7, nx_bound * 8, &po));
     hipLaunchKernelGGL(m_head_flag_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs, m, 0, (uint32_t*)fl);
     SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, tot));
     hipLaunchKernelGGL(m_compact_vals_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint64_t*)cs,
@@ -2075,6 +2300,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, m, tot + 1));
     hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
                        (const uint32_t*)ps, &d_ctl->mu, m, &d_ctl->ng, (uint32_t*)gs);
+    }
     hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx_bound)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                        (const uint32_t*)gs, &d_ctl->ng, nx_bound, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
                        (uint64_t*)gpairs, &d_ctl->rows);
@@ -2084,7 +2310,9 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     void* mailp;
     SHZ_TRY(shz_mailbox(ctx, sizeof(mctl), &mailp));
     SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, sizeof(mctl), hipMemcpyDeviceToHost, ctx->stream));
+    if (trace) tr1 = now_s();
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace) tr2 = now_s();
     const mctl h = *(const mctl*)mailp;
     if (h.err[0]) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query offsets must be < 2^%d frames", QOFF_BITS);
     const uint64_t mu = h.mu;
@@ -2161,7 +2389,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       void* hb;
       SHZ_TRY(shz_mailbox(ctx, rb_bytes, &hb));
       SHZ_HIP(ctx, hipMemcpyAsync(hb, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (trace) tr3 = now_s();
       SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (trace)
+        fprintf(stderr, "match trace: head enqueue %.1f us, wait %.1f us, tail enqueue %.1f us, wait %.1f us (P %llu)\n",
+                (tr1 - tr0) * 1e6, (tr2 - tr1) * 1e6, (tr3 - tr2) * 1e6, (now_s() - tr3) * 1e6, (unsigned long long)P);
       const uint64_t* h_np = (const uint64_t*)hb;
       const uint32_t* h_sid = (const uint32_t*)(h_np + nq);
       const uint32_t *h_delta = h_sid + nres, *h_al = h_delta + nres, *h_dd = h_al + nres, *h_n = h_dd + nres, *h_nh = h_n + nq;
