@@ -165,6 +165,11 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
   if (ctx->mail) (void)hipHostFree(ctx->mail);
+  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->ev_stft[i]) (void)hipEventDestroy(ctx->ev_stft[i]);
+    if (ctx->ev_free[i]) (void)hipEventDestroy(ctx->ev_free[i]);
+  }
   for (int i = 0; i < 2; ++i) {
     if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
     if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);

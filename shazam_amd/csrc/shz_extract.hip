@@ -816,8 +816,9 @@ struct sub_batch {
 };
 
 static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t n_clips, uint64_t bytes_per_frame,
-                                std::vector<sub_batch>& out) {
+                                std::vector<sub_batch>& out, uint64_t frame_cap = 0) {
   uint64_t max_frames = ctx->ws_limit / bytes_per_frame;
+  if (frame_cap && frame_cap < max_frames) max_frames = frame_cap;
   if (max_frames > (1u << 20)) max_frames = 1u << 20;  // mask words, peaks < 2^32 (hash count checked per sub-batch)
   if (max_frames < 64) max_frames = 64;
   sub_batch cur{0, 0, 0};
@@ -852,7 +853,8 @@ struct sub_dev {
 // No host synchronisation: the host-side image of the tables is handed to `keep`, which the caller holds until the
 // call's final sync (a small pageable hipMemcpyAsync may or may not have staged its source when it returns).
 static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_batch& sb, uint64_t pcm_base_off,
-                           uint32_t n_slabs, uint32_t wg_per_cu, sub_dev& sd, std::vector<std::vector<uint64_t>>& keep) {
+                           uint32_t n_slabs, uint32_t wg_per_cu, sub_dev& sd, std::vector<std::vector<uint64_t>>& keep,
+                           int slot = SHZ_WS_META) {
   const uint32_t nc = sb.c1 - sb.c0;
   sd.foff.assign(nc + 1, 0);
   std::vector<peak_seg> segs;
@@ -878,7 +880,7 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
   memcpy(&blob[2 * (uint64_t)nc], sd.foff.data(), (nc + 1) * 4);
   if (!segs.empty()) memcpy(&blob[2 * (uint64_t)nc + foff_words], segs.data(), segs.size() * sizeof(peak_seg));
   void* p0;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_META, blob.size() * 8 + 64, &p0));
+  SHZ_TRY(shz_ws_reserve(ctx, slot, blob.size() * 8 + 64, &p0));
   sd.d_soff = (uint64_t*)p0;
   sd.d_len = sd.d_soff + nc;
   sd.d_foff = (uint32_t*)(sd.d_len + nc);
@@ -890,7 +892,7 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
 
 // PCM of the sub-batch on the device: either the caller's device buffer or a staged copy
 static int32_t stage_pcm(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, const sub_batch& sb,
-                         uint32_t flags, const int16_t** d_pcm, uint64_t* base_off) {
+                         uint32_t flags, const int16_t** d_pcm, uint64_t* base_off, int slot = SHZ_WS_PCM) {
   const uint64_t s0 = clip_off[sb.c0], s1 = clip_off[sb.c1];
   if (flags & SHZ_PCM_DEVICE) {
     *d_pcm = pcm;
@@ -898,7 +900,7 @@ static int32_t stage_pcm(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_
     return SHZ_OK;
   }
   void* p;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PCM, (s1 - s0) * 2 + 64, &p));
+  SHZ_TRY(shz_ws_reserve(ctx, slot, (s1 - s0) * 2 + 64, &p));
   if (s1 > s0) SHZ_HIP(ctx, shz_memcpy(ctx, p, pcm + s0, (s1 - s0) * 2, hipMemcpyHostToDevice));
   *d_pcm = (const int16_t*)p;
   *base_off = s0;
@@ -922,14 +924,14 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
 }
 
 template <typename T>
-static int32_t launch_stft(shz_ctx* ctx, const stft_args& a) {
+static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 0) {
   shz_prof_scope ps(ctx, 0);
   static const int wgs_per_cu = [] {  // tuning knob: resident stft workgroups per CU (LDS allows 3)
     const char* e = getenv("SHZ_STFT_WGS_PER_CU");
     const int v = e ? atoi(e) : 3;
     return v >= 1 && v <= 3 ? v : 3;
   }();
-  uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * wgs_per_cu;
+  uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * (wgs_override ? wgs_override : wgs_per_cu);
   if (grid > a.total_frames) grid = a.total_frames;
   grid = (grid + 7) & ~7u;  // multiple of 8: see the XCD-aware frame map in the kernel
   hipLaunchKernelGGL(stft_psd_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, a);
@@ -1121,8 +1123,33 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
                             uint64_t cap, xctl* hctl) {
   const bool out_dev = (flags & SHZ_OUT_DEVICE) != 0;
   const mask_geom mg = xp.f32 ? mg_f32(p32_nw()) : MG_F64;
+  // Two-stream pipeline (fp32 staging; OFF unless SHZ_OVERLAP_SPLIT >= 2): the batch is cut into that many sub-batches
+  // and the STFT of sub-batch i+1 runs on a second stream beside peak picking and pair hashing of sub-batch i.
+  // stft_psd is VALU/LDS-bound with HBM idle, peak_pick32 waits on memory with the VALU idle, and at two STFT workgroups
+  // per CU both fit a CU together -- but measured on 1,000 x 30 s clips the step does not get shorter: 7.07 ms in
+  // sequence, 7.10 with 2 sub-batches, 8.05 with 4, 7.58 with 8, 9.03 with 16.  peak_pick32 hides its memory latency
+  // with many waves, and beside the STFT it gets one wave per SIMD (2.1 -> 4-6 ms while the STFT goes 4.4 -> 4.7).
+  static const int ov_split = [] { const char* e = getenv("SHZ_OVERLAP_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+  uint64_t frames_total = 0;
+  for (uint32_t c = 0; c < n_clips; ++c) frames_total += shz_frame_count(clip_off[c + 1] - clip_off[c]);
+  const bool want_overlap = xp.f32 && ov_split >= 2 && frames_total >= 65536;
   std::vector<sub_batch> subs;
-  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, xp.f32 ? (uint64_t)P32_STRIDE * 4 : (uint64_t)DB_STRIDE * 8, subs));
+  SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, xp.f32 ? (uint64_t)P32_STRIDE * 4 : (uint64_t)DB_STRIDE * 8, subs,
+                           want_overlap ? (frames_total + ov_split - 1) / ov_split : 0));
+  const bool overlap = want_overlap && subs.size() >= 2;
+  if (overlap && !ctx->stream2) {
+    SHZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      SHZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stft[i], hipEventDisableTiming));
+      SHZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
+    }
+  }
+  if (overlap) {  // the second stream starts behind everything queued on the first one (the caller's PCM may still be in the making)
+    SHZ_HIP(ctx, hipEventRecord(ctx->ev_free[0], ctx->stream));
+    SHZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_free[0], 0));
+  }
+  // whatever way this pass ends, the second stream is idle afterwards (workspace slots may be re-allocated by the next call)
+  struct s2_guard { shz_ctx* c; bool on; ~s2_guard() { if (on && c->stream2) (void)hipStreamSynchronize(c->stream2); } } s2g{ctx, overlap};
   void *p_ctl, *p_offs;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, sizeof(xctl) + 64, &p_ctl));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
@@ -1141,33 +1168,76 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
   double p_lo, p_hi;
   threshold_band(amp_min, &p_lo, &p_hi);
   std::vector<std::vector<uint64_t>> keep;
-  for (const sub_batch& sb : subs) {
-    const uint32_t nc = sb.c1 - sb.c0;
-    const int16_t* d_pcm;
+  // stage A of a sub-batch: PCM + tables on the device, STFT.  With the pipeline on it is issued on the second stream,
+  // into the buffers of the sub-batch's parity, one sub-batch ahead of stage B.
+  struct sub_state { sub_dev sd; const int16_t* d_pcm; void* d_pw; stft_args sa; };
+  std::vector<sub_state> st(subs.size());
+  const uint64_t pw_bytes_per_frame = xp.f32 ? (uint64_t)P32_STRIDE * 4 : (uint64_t)DB_STRIDE * 8;
+  if (overlap) {  // every buffer of both parities at its final size before anything is in flight on two streams
+    uint64_t fmax = 0, smax = 0, cmax = 0;
+    for (const sub_batch& sb : subs) {
+      fmax = std::max<uint64_t>(fmax, sb.frames);
+      smax = std::max<uint64_t>(smax, clip_off[sb.c1] - clip_off[sb.c0]);
+      cmax = std::max<uint64_t>(cmax, sb.c1 - sb.c0);
+    }
+    void* dummy;
+    const uint64_t meta_bound = (3 * cmax + fmax / PK_SEG + cmax + 64) * 16;
+    for (int par = 0; par < 2; ++par) {
+      SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_DB2 : SHZ_WS_DB, fmax * pw_bytes_per_frame, &dummy));
+      SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_META_B : SHZ_WS_META, meta_bound, &dummy));
+      if (!(flags & SHZ_PCM_DEVICE)) SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_PCM_B : SHZ_WS_PCM, smax * 2 + 64, &dummy));
+    }
+  }
+  auto stage_a = [&](size_t i) -> int32_t {
+    const sub_batch& sb = subs[i];
+    const int par = overlap ? (int)(i & 1) : 0;
+    hipStream_t main_stream = ctx->stream;
+    struct swap_guard { shz_ctx* c; hipStream_t keep; ~swap_guard() { c->stream = keep; } } sg{ctx, main_stream};
+    if (overlap) {
+      ctx->stream = ctx->stream2;   // copies, profiling events and the launch below go to the second stream
+      if (i >= 2) SHZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_free[par], 0));   // stage B of sub-batch i-2 is done with these buffers
+    }
+    sub_state& x = st[i];
     uint64_t base;
-    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &d_pcm, &base));
-    sub_dev sd;
-    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, mg.n_slabs, xp.f32 ? 12 / mg.nw : 3, sd, keep));
+    SHZ_TRY(stage_pcm(ctx, pcm, clip_off, sb, flags, &x.d_pcm, &base, par ? SHZ_WS_PCM_B : SHZ_WS_PCM));
+    SHZ_TRY(upload_meta(ctx, clip_off, sb, base, mg.n_slabs, xp.f32 ? 12 / mg.nw : 3, x.sd, keep, par ? SHZ_WS_META_B : SHZ_WS_META));
+    SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_DB2 : SHZ_WS_DB, (uint64_t)sb.frames * pw_bytes_per_frame, &x.d_pw));
+    x.sa = make_stft_args(ctx, x.d_pcm, x.sd, sb.c1 - sb.c0, sb.frames, fs, x.d_pw);
+    if (xp.f32) SHZ_TRY(launch_stft<float>(ctx, x.sa, overlap ? 2 : 0));
+    else SHZ_TRY(launch_stft<double>(ctx, x.sa));
+    if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_stft[par], ctx->stream2));
+    return SHZ_OK;
+  };
+  SHZ_TRY(stage_a(0));
+  for (size_t si = 0; si < subs.size(); ++si) {
+    const sub_batch& sb = subs[si];
+    if (overlap) {
+      if (si + 1 < subs.size()) SHZ_TRY(stage_a(si + 1));
+      SHZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_stft[si & 1], 0));
+    } else if (si > 0) {
+      SHZ_TRY(stage_a(si));
+    }
+    const uint32_t nc = sb.c1 - sb.c0;
+    const sub_dev& sd = st[si].sd;
+    void* d_pw = st[si].d_pw;
     const uint64_t n_words = (uint64_t)sb.frames * mg.n_slabs * mg.nw;
     if (n_words >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "too many mask words in one sub-batch");
     const uint64_t cap_peaks64 = (uint64_t)sb.frames * xp.peaks_per_frame + 4096;
     if (cap_peaks64 * (fan > 1 ? fan - 1 : 1) >= (1ull << 32))
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "sub-batch of %u frames may yield 2^32 hashes; lower the workspace limit", sb.frames);
     const uint32_t cap_peaks = (uint32_t)cap_peaks64;
-    void *d_pw, *d_mask, *d_woff, *d_und, *pf, *pt, *pc, *ft;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)sb.frames * (xp.f32 ? P32_STRIDE * 4 : DB_STRIDE * 8), &d_pw));
+    void *d_mask, *d_woff, *d_und, *pf, *pt, *pc, *ft;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MASK, n_words * 8, &d_mask));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, n_words * 4, &d_woff));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, (uint64_t)cap_peaks * 2 + 64, &pf));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_T, (uint64_t)cap_peaks * 4 + 64, &pt));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(nc + 1) * 4 + 64, &pc));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)sb.frames * 4 + 64, &ft));
-    const stft_args sa = make_stft_args(ctx, d_pcm, sd, nc, sb.frames, fs, d_pw);
+    const stft_args& sa = st[si].sa;
     if (xp.f32) {
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_UND, (uint64_t)UND_CAP * 8, &d_und));
       hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);
       SHZ_HIP(ctx, hipMemsetAsync(d_mask, 0, n_words * 8, ctx->stream));  // peak_pick32 writes non-zero words only
-      SHZ_TRY(launch_stft<float>(ctx, sa));
       {
         shz_prof_scope ps(ctx, 1);
         p32_args pa;
@@ -1212,7 +1282,6 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
         SHZ_HIP(ctx, hipGetLastError());
       }
     } else {
-      SHZ_TRY(launch_stft<double>(ctx, sa));
       {
         shz_prof_scope ps(ctx, 1);
         hipLaunchKernelGGL(peak_pick_kernel<true>, dim3(mg.n_slabs, sd.n_segs), dim3(256), 0, ctx->stream,
@@ -1250,6 +1319,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
                          (const uint16_t*)pf, (const uint32_t*)pt, cap_peaks, (uint16_t*)o_a, (uint32_t*)o_b, o_cap);
       hipLaunchKernelGGL(xctl_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, false);
       SHZ_HIP(ctx, hipGetLastError());
+      if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_free[si & 1], ctx->stream));   // this parity's buffers are free again
       continue;
     }
     {
@@ -1274,6 +1344,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
       hipLaunchKernelGGL(xctl_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, true);
       SHZ_HIP(ctx, hipGetLastError());
     }
+    if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_free[si & 1], ctx->stream));   // this parity's buffers are free again
   }
   // The one read-back of the pass, into pinned memory: control block | per-clip offsets | for small host outputs the
   // entries themselves (they ride along instead of costing a second round trip once the count is known).

@@ -62,6 +62,9 @@ enum {
   SHZ_WS_SORT_C,
   SHZ_WS_SORT_D,
   SHZ_WS_SORT_H,
+  SHZ_WS_DB2,        // second staged spectrogram: stft of sub-batch i+1 runs beside peak picking of sub-batch i
+  SHZ_WS_META_B,
+  SHZ_WS_PCM_B,
   SHZ_WS_CTL,        // device control block of the extraction pass (xctl)
   SHZ_WS_OFFS,       // per-clip output offsets (u64)
   SHZ_WS_UND,        // undecided cells of fp32 peak picking
@@ -99,6 +102,8 @@ struct shz_ctx {
   void* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
+  hipStream_t stream2 = nullptr;   // second stream of the extraction pipeline (created on first use)
+  hipEvent_t ev_stft[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   void* mail = nullptr;         // shz_mailbox
   uint64_t mail_cap = 0;
 };
