@@ -1203,7 +1203,8 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
     SHZ_TRY(upload_meta(ctx, clip_off, sb, base, mg.n_slabs, xp.f32 ? 12 / mg.nw : 3, x.sd, keep, par ? SHZ_WS_META_B : SHZ_WS_META));
     SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_DB2 : SHZ_WS_DB, (uint64_t)sb.frames * pw_bytes_per_frame, &x.d_pw));
     x.sa = make_stft_args(ctx, x.d_pcm, x.sd, sb.c1 - sb.c0, sb.frames, fs, x.d_pw);
-    if (xp.f32) SHZ_TRY(launch_stft<float>(ctx, x.sa, overlap ? 2 : 0));
+    static const int ov_wgs = [] { const char* e = getenv("SHZ_OVERLAP_STFT_WGS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 3 ? v : 2; }();
+    if (xp.f32) SHZ_TRY(launch_stft<float>(ctx, x.sa, overlap ? ov_wgs : 0));
     else SHZ_TRY(launch_stft<double>(ctx, x.sa));
     if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_stft[par], ctx->stream2));
     return SHZ_OK;
