@@ -722,6 +722,7 @@ __global__ void xctl_after_peaks_kernel(xctl* c, uint32_t cap_peaks, uint32_t un
 __global__ void xctl_offsets_kernel(const xctl* c, bool hashes, const uint32_t* __restrict__ rel, uint32_t nc,
                                     uint32_t c0, unsigned long long* __restrict__ out64) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && c0 == 0) out64[0] = 0;
   if (i >= nc) return;
   out64[c0 + i + 1] = (hashes ? c->hash_base : c->peak_base) + rel[i + 1];
 }
@@ -1155,8 +1156,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
   xctl* d_ctl = (xctl*)p_ctl;
   unsigned long long* d_offs = (unsigned long long*)p_offs;
-  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, sizeof(xctl), ctx->stream));
-  SHZ_HIP(ctx, hipMemsetAsync(d_offs, 0, 8, ctx->stream));
+  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, sizeof(xctl), ctx->stream));   // (offs[0] = 0 is written by xctl_offsets_kernel)
   // where the entries go: the caller's device arrays, or staging arrays that are copied out after the final sync
   void *o_a = want_hashes ? (void*)key32 : (void*)peak_f, *o_b = want_hashes ? (void*)t1 : (void*)peak_t;
   uint64_t o_cap = cap;
@@ -1237,7 +1237,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
     const stft_args& sa = st[si].sa;
     if (xp.f32) {
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_UND, (uint64_t)UND_CAP * 8, &d_und));
-      hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);
+      if (si) hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);   // (the block starts zeroed)
       SHZ_HIP(ctx, hipMemsetAsync(d_mask, 0, n_words * 8, ctx->stream));  // peak_pick32 writes non-zero words only
       {
         shz_prof_scope ps(ctx, 1);
@@ -1256,6 +1256,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
           case 14: launch_pick32<1, 4>(ctx, pa, sd.n_segs); break;
           case 23: launch_pick32<2, 3>(ctx, pa, sd.n_segs); break;
           case 33: launch_pick32<3, 3>(ctx, pa, sd.n_segs); break;
+          case 34: launch_pick32<3, 4>(ctx, pa, sd.n_segs); break;
           case 43: launch_pick32<4, 3>(ctx, pa, sd.n_segs); break;
           case 44: launch_pick32<4, 4>(ctx, pa, sd.n_segs); break;
           case 63: launch_pick32<6, 3>(ctx, pa, sd.n_segs); break;

@@ -1952,6 +1952,13 @@ __device__ __forceinline__ void m_query_groups(const uint32_t* __restrict__ qsta
   }
 }
 
+// qstart[0..nq) = "no group yet", the counter of long groups behind it = 0
+__global__ void m_tail_init_kernel(uint32_t* __restrict__ qstart, uint32_t nq) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) qstart[i] = 0xFFFFFFFFu;
+  else if (i == nq) qstart[nq] = 0u;
+}
+
 // one workgroup per query: top-n groups by (count desc, sid asc) over the packed group summaries
 __global__ __launch_bounds__(256) void m_topn_kernel(const uint32_t* __restrict__ qstart,
                                                      const unsigned long long* __restrict__ G, m_bits mb,
@@ -2128,8 +2135,7 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
   hipLaunchKernelGGL(m_gcount_kernel, dim3(nb), dim3(256), 0, ctx->stream, vs, P, mb.dbits + 1, wcnt);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u32(ctx, wcnt, wbase, nw, d_tot));   // *d_tot = G, the number of (query, song) groups: stays on the device
-  SHZ_HIP(ctx, hipMemsetAsync(qstart, 0xFF, (uint64_t)nq * 4, ctx->stream));
-  SHZ_HIP(ctx, hipMemsetAsync(long_cnt, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(m_tail_init_kernel, dim3(nblk((uint64_t)nq + 1)), dim3(256), 0, ctx->stream, qstart, nq);   // qstart = none, long_cnt = 0
   // G <= P, and a group needs a vote per song: the record arrays are sized by that bound instead of a read-back of G
   const uint64_t Gb = P;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, Gb * 8, &gh));
@@ -2190,9 +2196,10 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   const uint32_t *d_key = key32, *d_qo = q_off;
   void* d_segs;
   const uint64_t* d_qoff_all = nullptr;   // query_off[0 .. n_queries] on the device, when it went with the packed upload
+  mctl* d_ctl_packed = nullptr;           // ... and a zeroed control block for the first sub-batch
   const uint64_t seg_bytes = (sizeof(shz_seg_dev) * (uint64_t)nseg + 255) & ~255ull;
   const uint64_t qoff_bytes = (((uint64_t)n_queries + 1) * 8 + 255) & ~255ull;
-  const uint64_t pk_bytes = seg_bytes + qoff_bytes + ((h1 * 4 + 255) & ~255ull) * 2;
+  const uint64_t pk_bytes = seg_bytes + qoff_bytes + ((h1 * 4 + 255) & ~255ull) * 2 + 256;   // + a zeroed mctl at the end
   if (!(flags & SHZ_IN_DEVICE) && pk_bytes <= (4ull << 20)) {
     void *hm, *dm;
     SHZ_TRY(shz_mailbox(ctx, pk_bytes, &hm));
@@ -2205,6 +2212,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       memcpy(hp + ko, key32, h1 * 4);
       memcpy(hp + oo, q_off, h1 * 4);
     }
+    memset(hp + pk_bytes - 256, 0, 256);
+    d_ctl_packed = (mctl*)((char*)dm + pk_bytes - 256);
     SHZ_HIP(ctx, hipMemcpyAsync(dm, hm, pk_bytes, hipMemcpyHostToDevice, ctx->stream));
     d_segs = dm;
     d_qoff_all = (const uint64_t*)((char*)dm + seg_bytes);
@@ -2243,11 +2252,16 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, (uint64_t)(nq + 1) * 8, &d_qoff));
       SHZ_HIP(ctx, shz_memcpy(ctx, d_qoff, query_off + q0, (uint64_t)(nq + 1) * 8, hipMemcpyHostToDevice));
     }
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &ctl_p));
+    if (d_ctl_packed && q0 == 0) {
+      ctl_p = d_ctl_packed;               // arrived zeroed with the upload
+      d_ctl_packed = nullptr;             // (a retry with fewer queries, or a later sub-batch, zeroes its own)
+    } else {
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 256, &ctl_p));
+      SHZ_HIP(ctx, hipMemsetAsync(ctl_p, 0, 256, ctx->stream));
+    }
     mctl* d_ctl = (mctl*)ctl_p;
     uint64_t* tot = (uint64_t*)ctl_p;      // tot[0..4] = mu, ng, rows, P, G
     uint32_t* err = d_ctl->err;
-    SHZ_HIP(ctx, hipMemsetAsync(ctl_p, 0, 256, ctx->stream));
     if (m == 0) {
       for (uint32_t q = 0; q < nq; ++q) {
         if (out_nres) out_nres[q0 + q] = 0;
@@ -2355,9 +2369,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     uint64_t* d_np = (uint64_t*)rb;
     uint32_t* r_sid = (uint32_t*)(d_np + nq);
     uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
-    hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
-                       (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
-    SHZ_HIP(ctx, hipGetLastError());
+    if (nq > 1) {   // one query: its counts are the totals the host already holds
+      hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
+                         (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
     const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
     void* tile_x = nullptr;
     if (P > 0 && (!vs_out || vs_out->count + P <= vs_out->cap)) {
@@ -2397,8 +2413,13 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       const uint64_t* h_np = (const uint64_t*)hb;
       const uint32_t* h_sid = (const uint32_t*)(h_np + nq);
       const uint32_t *h_delta = h_sid + nres, *h_al = h_delta + nres, *h_dd = h_al + nres, *h_n = h_dd + nres, *h_nh = h_n + nq;
-      if (out_npairs) memcpy(out_npairs + q0, h_np, (uint64_t)nq * 8);
-      if (out_nhash) memcpy(out_nhash + q0, h_nh, (uint64_t)nq * 4);
+      if (nq == 1) {
+        if (out_npairs) out_npairs[q0] = P;
+        if (out_nhash) out_nhash[q0] = (uint32_t)mu;
+      } else {
+        if (out_npairs) memcpy(out_npairs + q0, h_np, (uint64_t)nq * 8);
+        if (out_nhash) memcpy(out_nhash + q0, h_nh, (uint64_t)nq * 4);
+      }
       if (!vs_out) {
         const uint64_t o0 = (uint64_t)q0 * topn;
         memcpy(out_sid + o0, h_sid, nres * 4);
