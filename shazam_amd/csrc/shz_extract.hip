@@ -1111,7 +1111,8 @@ struct xparams {
 
 template <int NW, int OCC>
 static void launch_pick32(shz_ctx* ctx, const p32_args& pa, uint32_t n_segs) {
-  hipLaunchKernelGGL((peak_pick32_kernel<NW, OCC>), dim3(pa.n_slabs, n_segs), dim3(64 * NW), 0, ctx->stream, pa);
+  const uint32_t per_xcd = (n_segs + 7) >> 3;   // segments per XCD; 8 * per_xcd * n_slabs workgroups, see the kernel's work map
+  hipLaunchKernelGGL((peak_pick32_kernel<NW, OCC>), dim3(8 * per_xcd * pa.n_slabs), dim3(64 * NW), 0, ctx->stream, pa);
 }
 static int p32_occ() {
   static const int v = [] { const char* e = getenv("SHZ_PEAK_OCC"); const int x = e ? atoi(e) : 4; return x >= 3 && x <= 6 ? x : 4; }();
@@ -1245,6 +1246,7 @@ static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* cl
         pa.A = (const float*)d_pw;
         pa.segs = sd.d_segs;
         pa.n_slabs = mg.n_slabs;
+        pa.n_segs = sd.n_segs;
         pa.p_lo = (float)p_lo;   // fp32(P) < fp32(p_lo) => P < p_lo; fp32(P) > fp32(p_hi) => P > p_hi (monotone rounding)
         pa.p_hi = (float)p_hi;
         pa.mask = (uint64_t*)d_mask;
