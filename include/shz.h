@@ -95,6 +95,11 @@ int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, fl
  * bytes per key.  keys / vals are HOST arrays, sorted in place.  n < 2^32. */
 int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_bytes, uint64_t n, uint32_t bit_lo,
                        uint32_t bit_hi);
+/* The 4-byte form the vote uses when a pass's query index, song id and offset delta fit 31 bits (tests / tools): stable
+ * sort of n 32-bit keys on bits [bit_lo, bit_hi), written as 64-bit keys `key + add` (the last pass widens).
+ * keys / out64 are HOST arrays.  n < 2^32. */
+int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, uint64_t add,
+                        uint64_t* out64);
 
 /* Query preparation (bench / tests): exact sum of squares of each clip (device PCM, clip-major, equal
  * lengths) to HOST, and out = clip(rint(sig + scale[c] * noise)) on the device: the digital form of

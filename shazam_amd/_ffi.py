@@ -41,6 +41,7 @@ SIGNATURES = {
     "shz_mix_i16": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, f64p, vp]),
     "shz_membw": (C.c_int32, [vp, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
     "shz_sort_pairs": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "shz_sort_keys32": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
@@ -203,6 +204,13 @@ class Context:
         g = C.c_float()
         self.check(lib().shz_membw(self.h, int(mode), int(nbytes), int(iters), C.byref(g)))
         return float(g.value)
+
+    def sort_keys32(self, keys: np.ndarray, bit_lo: int = 0, bit_hi: int = 32, add: int = 0) -> np.ndarray:
+        """Stable device radix sort of uint32 keys on bits [bit_lo, bit_hi); returns uint64 keys `key + add`."""
+        k = np.ascontiguousarray(keys, np.uint32)
+        out = np.empty(len(k), np.uint64)
+        self.check(lib().shz_sort_keys32(self.h, ptr(k), len(k), int(bit_lo), int(bit_hi), int(add), ptr(out)))
+        return out
 
     def sort_pairs(self, keys: np.ndarray, vals=None, bit_lo: int = 0, bit_hi: int = 64):
         """Stable device radix sort of uint64 keys on bits [bit_lo, bit_hi), with an optional

@@ -146,6 +146,11 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, uint64_t n,
                      int bit_lo, int bit_hi, int* out_sel);
 
+// stable LSD radix sort of 4-byte keys on bits [bit_lo, bit_hi) (k0 <-> k1 ping-pong); the result is written to out64 as
+// 8-byte keys, key + add
+int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
+                           uint64_t add);
+
 // ---- RCCL helpers (shz_comm.hip) ----------------------------------------------------------
 int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks);
 shz_ctx* shz_comm_ctx(shz_comm* c);

@@ -436,6 +436,200 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
   return SHZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same sort for 4-BYTE keys (the votes of one or two queries fit 32 bits: song 20 + delta 10 + flag 1), keys only.
+// Half the bytes per pass; the LAST pass writes 8-byte keys, `key + add`, so that what follows the sort (the fold of the
+// votes, which wants the query index above the song id) reads the usual 64-bit layout.
+template <int BITS>
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist32_kernel(const uint32_t* __restrict__ keys, uint64_t n, int shift,
+                                                                    uint32_t dmask, uint32_t* __restrict__ hist,
+                                                                    uint32_t nblocks) {
+  constexpr uint32_t DIG = 1u << BITS;
+  __shared__ uint32_t h[DIG];
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) h[d] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+  if (base + SORT_TILE <= n) {  // whole tile: four keys per lane and load, all loads in flight before the first count
+    const uint4* k4 = (const uint4*)(keys + base);
+    uint4 x[SORT_ROUNDS / 4];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 4; ++r) x[r] = k4[r * SORT_THREADS + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 4; ++r) {
+      atomicAdd(&h[(x[r].x >> shift) & dmask], 1u);
+      atomicAdd(&h[(x[r].y >> shift) & dmask], 1u);
+      atomicAdd(&h[(x[r].z >> shift) & dmask], 1u);
+      atomicAdd(&h[(x[r].w >> shift) & dmask], 1u);
+    }
+  } else {
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+      const uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
+      if (i < n) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+// OT = uint32_t: an ordinary pass; OT = uint64_t: the last pass, out = key + add
+template <typename OT, int BITS>
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_kernel(const uint32_t* __restrict__ keys, OT* __restrict__ okeys,
+                                                                       uint64_t n, int shift, uint32_t dmask,
+                                                                       const uint32_t* __restrict__ offs, uint32_t nblocks,
+                                                                       uint64_t add) {
+  constexpr uint32_t DIG = 1u << BITS;
+  constexpr int DPT = DIG / SORT_THREADS;
+  __shared__ uint32_t skey[SORT_TILE];
+  __shared__ uint32_t gbase[DIG];
+  __shared__ uint16_t lstart[DIG];
+  __shared__ uint16_t wrun[4][DIG];
+  __shared__ uint32_t scan_tmp[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+  const uint32_t tile_n = (uint32_t)(n - base < SORT_TILE ? n - base : SORT_TILE);
+  constexpr int ROWS = SORT_TILE / SORT_THREADS;
+  uint32_t k[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    k[r] = li < tile_n ? keys[base + li] : 0;
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) wrun[w][threadIdx.x * DPT + i] = 0;
+  {
+    uint32_t g0[DPT], c[DPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const uint64_t f = (uint64_t)(threadIdx.x * DPT + i) * nblocks + blockIdx.x;
+      g0[i] = offs[f];
+      const uint32_t g1 = (f + 1 < (uint64_t)DIG * nblocks) ? offs[f + 1] : (uint32_t)n;
+      c[i] = g1 - g0[i];
+      sum += c[i];
+    }
+    uint32_t tot;
+    uint32_t ls = block_excl_scan<uint32_t>(sum, &tot, scan_tmp);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      gbase[threadIdx.x * DPT + i] = g0[i];
+      lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
+      ls += c[i];
+    }
+  }
+  __syncthreads();
+  uint32_t rank[ROWS];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    const bool valid = li < tile_n;
+    const uint32_t d = (k[r] >> shift) & dmask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    const uint32_t run = wrun[wave][d];
+    rank[r] = run + rk;
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) {
+    const uint32_t d = threadIdx.x * DPT + i;
+    const uint32_t c0 = wrun[0][d], c1 = wrun[1][d], c2 = wrun[2][d];
+    const uint32_t ls = lstart[d];
+    wrun[0][d] = (uint16_t)ls;
+    wrun[1][d] = (uint16_t)(ls + c0);
+    wrun[2][d] = (uint16_t)(ls + c0 + c1);
+    wrun[3][d] = (uint16_t)(ls + c0 + c1 + c2);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    if (li < tile_n) {
+      const uint32_t d = (k[r] >> shift) & dmask;
+      skey[wrun[wave][d] + rank[r]] = k[r];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
+    const uint32_t kk = skey[i];
+    const uint32_t d = (kk >> shift) & dmask;
+    okeys[gbase[d] + (i - lstart[d])] = (OT)((uint64_t)kk + add);
+  }
+}
+
+// widen in place of a sort: out[i] = in[i] + add (when no bit needs sorting)
+__global__ void widen32_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n, uint64_t add) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint64_t)in[i] + add;
+}
+
+int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
+                           uint64_t add) {
+  if (n == 0) return SHZ_OK;
+  if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: n must be < 2^32 (got %llu)", (unsigned long long)n);
+  if (bit_hi > 32) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: bits [%d, %d)", bit_lo, bit_hi);
+  if (bit_hi <= bit_lo) {
+    hipLaunchKernelGGL(widen32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)k0, out64, n, add);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
+  }
+  const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+  const int bits = bit_hi - bit_lo;
+  const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
+  const bool wide = np9 < np8;
+  void* hist;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, ((uint64_t)nblocks << (wide ? 9 : 8)) * 4, &hist));
+  uint32_t *kin = k0, *kout = k1;
+  int left = wide ? np9 : np8;
+  for (int shift = bit_lo; shift < bit_hi; --left) {
+    const int w = wide ? (bit_hi - shift + left - 1) / left : 8;
+    const int wb = w == 9 ? 9 : 8;
+    const uint32_t dmask = (1u << std::min(wb, bit_hi - shift)) - 1u;
+    const bool last = shift + wb >= bit_hi;
+    if (wb == 9) {
+      hipLaunchKernelGGL(sort_hist32_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, n, shift, dmask, (uint32_t*)hist, nblocks);
+      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, (uint64_t)nblocks << 9, nullptr));
+      if (last) hipLaunchKernelGGL((sort_scatter32_kernel<uint64_t, 9>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, out64, n, shift, dmask, (const uint32_t*)hist, nblocks, add);
+      else hipLaunchKernelGGL((sort_scatter32_kernel<uint32_t, 9>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, shift, dmask, (const uint32_t*)hist, nblocks, (uint64_t)0);
+    } else {
+      hipLaunchKernelGGL(sort_hist32_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, n, shift, dmask, (uint32_t*)hist, nblocks);
+      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, (uint64_t)nblocks << 8, nullptr));
+      if (last) hipLaunchKernelGGL((sort_scatter32_kernel<uint64_t, 8>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, out64, n, shift, dmask, (const uint32_t*)hist, nblocks, add);
+      else hipLaunchKernelGGL((sort_scatter32_kernel<uint32_t, 8>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, shift, dmask, (const uint32_t*)hist, nblocks, (uint64_t)0);
+    }
+    SHZ_HIP(ctx, hipGetLastError());
+    shift += wb;
+    std::swap(kin, kout);
+  }
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
+                                   uint64_t add, uint64_t* out64) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (n == 0) return SHZ_OK;
+  if (!keys || !out64) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32: NULL buffer");
+  if (bit_hi > 32 || bit_lo > bit_hi) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32: bits [%u, %u)", bit_lo, bit_hi);
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void *k0, *o;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &o));
+  SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
+  SHZ_TRY(shz_sort_u32_widen(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, (uint64_t*)o, n, (int)bit_lo, (int)bit_hi, add));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out64, o, n * 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_bytes, uint64_t n, uint32_t bit_lo,
                                   uint32_t bit_hi) {
   if (!ctx) return SHZ_E_INVALID;

@@ -1562,11 +1562,12 @@ __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* _
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total, s);
 }
 
-__global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, uint32_t mu, const uint32_t* __restrict__ gs,
-                                     uint32_t ng, const uint64_t* __restrict__ po, uint32_t nseg, uint32_t nq,
-                                     uint32_t* __restrict__ nhash, uint64_t* __restrict__ npairs) {
+__global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, const mctl* __restrict__ ctl,
+                                     const uint32_t* __restrict__ gs, const uint64_t* __restrict__ po, uint32_t nseg,
+                                     uint32_t nq, uint32_t* __restrict__ nhash, uint64_t* __restrict__ npairs) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
+  const uint32_t mu = (uint32_t)ctl->mu, ng = (uint32_t)ctl->ng;
   // elements of q: E in [q << 52, (q+1) << 52)
   auto lb_e = [&](uint64_t target) {
     uint32_t l = 0, h = mu;
@@ -1594,11 +1595,12 @@ struct m_bits { int sb, dbits, qb; uint32_t bias; };  // bias = max query offset
 #define M_EXP_SUB 512   // sub-groups per tile that fit the LDS tables (more: the same search over global memory)
 
 // tile_x[t] = last x in [0, nx) with po[x] <= min(t * M_EXP_TILE, P - 1), t = 0 .. ntiles
-__global__ void m_tile_start_kernel(const uint64_t* __restrict__ po, uint32_t nx, uint64_t P, uint32_t ntiles,
+// (votes [v_lo, P) of the sub-batch: a vote pass may cover a range of queries only)
+__global__ void m_tile_start_kernel(const uint64_t* __restrict__ po, uint32_t nx, uint64_t v_lo, uint64_t P, uint32_t ntiles,
                                     uint32_t* __restrict__ tile_x) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > ntiles) return;
-  const uint64_t p = min((uint64_t)t * M_EXP_TILE, P - 1);
+  const uint64_t p = min(v_lo + (uint64_t)t * M_EXP_TILE, P - 1);
   uint32_t l = 0, h = nx;
   while (h - l > 1) {
     const uint32_t mid = l + ((h - l) >> 1);
@@ -1607,23 +1609,26 @@ __global__ void m_tile_start_kernel(const uint64_t* __restrict__ po, uint32_t nx
   tile_x[t] = l;
 }
 
-__device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t off, uint32_t first, m_bits mb, uint32_t q_base) {
-  const uint64_t q = (e >> QIDX_SHIFT) + q_base;
+__device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t off, uint32_t first, m_bits mb, int64_t q_base) {
+  const uint64_t q = (uint64_t)((int64_t)(e >> QIDX_SHIFT) + q_base);
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
   const uint64_t dprime = (uint64_t)off + mb.bias - qo;  // delta + bias >= 0
   return ((((q << mb.sb) | sid) << mb.dbits | dprime) << 1) | first;
 }
 
+// Votes [v_lo, P) of the sub-batch go to v[0 ..): VT = uint64_t, or uint32_t when a pass's queries, song ids and deltas
+// fit 31 bits (q_base then shifts the query index to the pass's first query).
+template <typename VT>
 __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
                                                        const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
                                                        const uint32_t* __restrict__ g_lo,
-                                                       const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t P,
-                                                       m_bits mb, uint32_t q_base, uint64_t* __restrict__ v) {
+                                                       const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                                       uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
   __shared__ uint64_t s_po[M_EXP_SUB], s_e[M_EXP_SUB];
   __shared__ uint32_t s_lo[M_EXP_SUB], s_e0[M_EXP_SUB], s_noff[M_EXP_SUB], s_sg[M_EXP_SUB];
   __shared__ const uint32_t* s_sid[SHZ_MAX_SEGS];
   __shared__ const uint32_t* s_off[SHZ_MAX_SEGS];
-  const uint64_t base = (uint64_t)blockIdx.x * M_EXP_TILE;
+  const uint64_t base = v_lo + (uint64_t)blockIdx.x * M_EXP_TILE;
   const uint64_t last = min(base + M_EXP_TILE, P) - 1;
   const uint32_t xA = tile_x[blockIdx.x], xB = tile_x[blockIdx.x + 1];  // sub-groups of the tile's pairs: [xA, xB]
   const uint32_t cnt = xB - xA + 1;
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
       const uint32_t row = s_lo[i] + ridx, sg = s_sg[i];
       const uint64_t out = m_vote(e, s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
       const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
-      if (pj < P) v[pj] = out;
+      if (pj < P) v[pj - v_lo] = (VT)out;
     }
     return;
   }
@@ -1691,7 +1696,7 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
     const uint32_t row = g_lo[x] + ridx;
     const uint64_t out = m_vote(E[e0 + oi], s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
     const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
-    if (pj < P) v[pj] = out;
+    if (pj < P) v[pj - v_lo] = (VT)out;
   }
 }
 
@@ -2112,6 +2117,9 @@ struct pair_sink {
 
 // sort the packed votes, fold every (query, sid) group into one record and pick the top-n per query into device
 // result arrays (r_*: nq*topn / nq entries, zeroed by the caller).  v0 holds the P votes, v1 is scratch of the same size.
+static int32_t vote_fold(shz_ctx* ctx, const uint64_t* vs, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
+                         uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n);
+
 static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
                          uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
   int sel = 0;
@@ -2124,7 +2132,12 @@ static int32_t vote_tail(shz_ctx* ctx, uint64_t* v0, uint64_t* v1, uint64_t P, u
   } else {
     SHZ_TRY(shz_sort_u64(ctx, v0, v1, nullptr, nullptr, 0, P, 1, mb.qb + mb.sb + mb.dbits + 1, &sel));
   }
-  const uint64_t* vs = sel ? v1 : v0;
+  return vote_fold(ctx, sel ? v1 : v0, P, nq, mb, topn, d_tot, r_sid, r_delta, r_al, r_dd, r_n);
+}
+
+// sorted votes -> one record per (query, song) group -> top-n per query
+static int32_t vote_fold(shz_ctx* ctx, const uint64_t* vs, uint64_t P, uint32_t nq, m_bits mb, uint32_t topn,
+                         uint64_t* d_tot, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n) {
   // group heads per wave -> first record slot of every wave -> one record per (query, sid) group
   const uint32_t nb = nblk((P + RG_PER - 1) / RG_PER), nw = nb * 4;
   void *wc, *gh, *gd, *gdd;
@@ -2320,10 +2333,27 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                        (uint64_t*)gpairs, &d_ctl->rows);
     SHZ_HIP(ctx, hipGetLastError());
     SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx_bound, tot + 3));
-    // the one read-back before the votes: their number sizes the vote buffers and the sort
+    // results and per-query counters in ONE device block: one fill before, one copy after.
+    // layout: npairs[nq] u64 | sid, delta, aligned, dedup [nq * topn] u32 each | nres[nq] | nhash[nq]
+    const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
+    const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8;
+    void* rb;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
+    SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));
+    uint64_t* d_np = (uint64_t*)rb;
+    uint32_t* r_sid = (uint32_t*)(d_np + nq);
+    uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
+    if (nq > 1) {   // one query: its counts are the totals
+      hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
+                         (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+    // the one read-back before the votes: their number sizes the vote buffers and the sort, their number per query
+    // plans the vote passes
     void* mailp;
-    SHZ_TRY(shz_mailbox(ctx, sizeof(mctl), &mailp));
+    SHZ_TRY(shz_mailbox(ctx, 256 + (uint64_t)nq * 8, &mailp));
     SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, sizeof(mctl), hipMemcpyDeviceToHost, ctx->stream));
+    if (nq > 1) SHZ_HIP(ctx, hipMemcpyAsync((char*)mailp + 256, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (trace) tr1 = now_s();
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) tr2 = now_s();
@@ -2359,47 +2389,78 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     ctx->st_rows += rows_total;
     ctx->st_pairs += P;
     ctx->st_keys += ng;
-    // results and per-query counters in ONE device block: one fill before, one copy after.
-    // layout: npairs[nq] u64 | sid, delta, aligned, dedup [nq * topn] u32 each | nres[nq] | nhash[nq]
-    const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
-    const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8;
-    void* rb;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
-    SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));
-    uint64_t* d_np = (uint64_t*)rb;
-    uint32_t* r_sid = (uint32_t*)(d_np + nq);
-    uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
-    if (nq > 1) {   // one query: its counts are the totals the host already holds
-      hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (uint32_t)mu,
-                         (const uint32_t*)gs, ng, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
-      SHZ_HIP(ctx, hipGetLastError());
-    }
-    const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
+    std::vector<uint64_t> h_votes(nq, P);   // votes per query (read back with the counts)
+    if (nq > 1) memcpy(h_votes.data(), (const char*)mailp + 256, (uint64_t)nq * 8);
     void* tile_x = nullptr;
-    if (P > 0 && (!vs_out || vs_out->count + P <= vs_out->cap)) {
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, ((uint64_t)ntiles + 1) * 4, &tile_x));
-      hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)po,
-                         (uint32_t)nx, P, ntiles, (uint32_t*)tile_x);
-    }
     if (P > 0 && vs_out) {
       // hand the votes over: expand straight into the caller's buffer, in the shared layout, with global query indices
       if (vs_out->count + P <= vs_out->cap) {
-        hipLaunchKernelGGL(m_expand_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                           (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
-                           (uint32_t)nseg, P, vs_out->lay, q0, vs_out->d_pairs + vs_out->count);
+        const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, ((uint64_t)ntiles + 1) * 4, &tile_x));
+        hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)po,
+                           (uint32_t)nx, (uint64_t)0, P, ntiles, (uint32_t*)tile_x);
+        hipLaunchKernelGGL(m_expand_kernel<uint64_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                           (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
+                           (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint64_t)0, P, vs_out->lay, (int64_t)q0,
+                           vs_out->d_pairs + vs_out->count);
         SHZ_HIP(ctx, hipGetLastError());
       }
       vs_out->count += P;  // keeps counting past cap: the caller learns the size it needs
     } else if (P > 0) {
-      // expand -> sort -> runs -> groups -> top-n.  E lives in one of SORT_A/B; the pair buffers use SORT_C/D.
-      void *v0, *v1;
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, P * 8, &v0));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, P * 8, &v1));
-      hipLaunchKernelGGL(m_expand_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const uint32_t*)gs,
-                         (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo, (const shz_seg_dev*)d_segs,
-                         (uint32_t)nseg, P, mb, 0u, (uint64_t*)v0);
-      SHZ_HIP(ctx, hipGetLastError());
-      SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, P, nq, mb, topn, tot + 4, r_sid, (int32_t*)r_delta, r_al, r_dd, r_n));
+      // expand -> sort -> groups -> top-n, in vote passes over ranges of queries.  4-BYTE votes when a pass's query
+      // index, the song id and the biased delta fit 31 bits (1M songs x 10 s queries: 1 + 20 + 10): half the bytes
+      // through expand and the sort passes, whose last pass widens to the 64-bit layout the fold reads.  Worth it only
+      // while a pass still has millions of votes; else one 8-byte pass over all queries.
+      struct vpass { uint32_t qa, qb; uint64_t v_lo, v_hi; };
+      std::vector<vpass> passes;
+      const int qbits32 = 31 - mb.sb - mb.dbits;
+      static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
+      bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0;
+      if (use32) {
+        uint64_t v = 0;
+        for (uint32_t qa = 0; qa < nq;) {
+          uint32_t qb = qa;
+          uint64_t pv = 0;
+          while (qb < nq && (qb - qa) < (1u << qbits32) && (qb == qa || pv + h_votes[qb] <= P_BUDGET)) pv += h_votes[qb++];
+          if (pv) passes.push_back(vpass{qa, qb, v, v + pv});
+          v += pv;
+          qa = qb;
+        }
+        if (force32 != 1 && P / std::max<size_t>(passes.size(), 1) < (1ull << 22)) use32 = false;   // small passes: launch-bound
+      }
+      if (!use32) { passes.clear(); passes.push_back(vpass{0, nq, 0, P}); }
+      uint64_t pmax = 0;
+      for (const vpass& vp : passes) pmax = std::max(pmax, vp.v_hi - vp.v_lo);
+      void *v0, *v1;   // E lives in one of SORT_A/B; the vote buffers use SORT_C/D
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, pmax * 8, &v0));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, pmax * 8, &v1));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, ((pmax + M_EXP_TILE - 1) / M_EXP_TILE + 1) * 4, &tile_x));   // (M5 belongs to the fold)
+      for (const vpass& vp : passes) {
+        const uint64_t pp = vp.v_hi - vp.v_lo;
+        const uint32_t nqp = vp.qb - vp.qa;
+        const uint32_t ntiles = (uint32_t)((pp + M_EXP_TILE - 1) / M_EXP_TILE);
+        m_bits mbp = mb;
+        if (use32) mbp.qb = nqp > 1 ? bits_for(nqp - 1) : 0;
+        hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)po,
+                           (uint32_t)nx, vp.v_lo, vp.v_hi, ntiles, (uint32_t*)tile_x);
+        uint32_t *rs = r_sid + (uint64_t)vp.qa * topn, *ra = r_al + (uint64_t)vp.qa * topn, *rd = r_dd + (uint64_t)vp.qa * topn;
+        int32_t* rdl = (int32_t*)r_delta + (uint64_t)vp.qa * topn;
+        if (use32) {
+          uint32_t* k32 = (uint32_t*)v0;   // two 4-byte buffers in SORT_C, the widened result in SORT_D
+          hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                             (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
+                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp, -(int64_t)vp.qa, k32);
+          SHZ_HIP(ctx, hipGetLastError());
+          SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, (uint64_t*)v1, pp, 1, mbp.qb + mbp.sb + mbp.dbits + 1, 0));
+          SHZ_TRY(vote_fold(ctx, (const uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
+        } else {
+          hipLaunchKernelGGL(m_expand_kernel<uint64_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                             (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
+                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp, (int64_t)0, (uint64_t*)v0);
+          SHZ_HIP(ctx, hipGetLastError());
+          SHZ_TRY(vote_tail(ctx, (uint64_t*)v0, (uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
+        }
+      }
     }
     {
       void* hb;

@@ -49,3 +49,21 @@ def test_sorted_and_constant_inputs():
     k, v = ctx.sort_pairs(const, np.arange(n, dtype=np.uint32), 0, 35)
     assert np.array_equal(k, const) and np.array_equal(v, np.arange(n, dtype=np.uint32))
     assert ctx.sort_pairs(np.zeros(0, np.uint64), None, 0, 64).size == 0
+
+
+@pytest.mark.parametrize("n", [1, 5, 4095, 4096, 4097, 70000, 3_000_001])
+@pytest.mark.parametrize("bits", [(0, 32), (1, 31), (1, 28), (3, 12), (0, 9), (5, 5), (1, 19)])
+def test_sort_keys32_against_numpy(n, bits):
+    """The 4-byte sort of the vote: stable on the chosen bit range, last pass widens and adds."""
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    lo, hi = bits
+    rng = np.random.default_rng(n * 131 + lo * 7 + hi)
+    k = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    if n > 10:
+        k[: n // 3] &= np.uint32(0xFF0)            # many equal digits: stability matters
+    add = int(rng.integers(0, 1 << 40)) << 8
+    got = ctx.sort_keys32(k, lo, hi, add)
+    field = (k >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1) if hi > lo else np.zeros(n, np.uint32)
+    want = k[np.argsort(field, kind="stable")].astype(np.uint64) + np.uint64(add)
+    assert np.array_equal(got, want)
