@@ -167,6 +167,8 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
   if (ctx->d_window) (void)hipFree(ctx->d_window);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
+  if (ctx->twin) { (void)shz_ctx_destroy(ctx->twin); ctx->twin = nullptr; }
+  if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
   if (ctx->mail) (void)hipHostFree(ctx->mail);
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
   for (int i = 0; i < 2; ++i) {
@@ -328,14 +330,22 @@ extern "C" int32_t shz_set_profiling(shz_ctx* ctx, int32_t enabled) {
     ctx->kernel_ms[i] = 0;
     ctx->kernel_launches[i] = 0;
   }
+  if (ctx->twin) (void)shz_set_profiling(ctx->twin, enabled);
   return SHZ_OK;
 }
 
 extern "C" int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t* launches) {
   if (!ctx || which < 0 || which >= 8) return SHZ_E_INVALID;
   prof_drain(ctx);
-  if (total_ms) *total_ms = ctx->kernel_ms[which];
-  if (launches) *launches = ctx->kernel_launches[which];
+  float ms = ctx->kernel_ms[which];
+  uint32_t n = ctx->kernel_launches[which];
+  if (ctx->twin) {   // the second pipeline of dual extraction passes
+    prof_drain(ctx->twin);
+    ms += ctx->twin->kernel_ms[which];
+    n += ctx->twin->kernel_launches[which];
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
   return SHZ_OK;
 }
 

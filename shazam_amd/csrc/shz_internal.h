@@ -104,6 +104,8 @@ struct shz_ctx {
   bool pin_busy[2] = {false, false};
   hipStream_t stream2 = nullptr;   // second stream of the extraction pipeline (created on first use)
   hipEvent_t ev_stft[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  shz_ctx* twin = nullptr;         // second pipeline of a dual extraction pass: own stream, own workspace (created on first use)
+  hipEvent_t ev_twin = nullptr;
   void* mail = nullptr;         // shz_mailbox
   uint64_t mail_cap = 0;
 };
