@@ -29,6 +29,7 @@ def per_launch(dirname, counter):
 
 def main():
     fdir, wdir, out, note = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] if len(sys.argv) > 4 else "")
+    frames_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else 644000
     f, w = per_launch(fdir, "FETCH_SIZE"), per_launch(wdir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -38,8 +39,8 @@ def main():
                "units": "bytes per launch (KiB counters x 1024); hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE per "
                         "MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); narrow loads are "
                         "uncalibrated, so raw and corrected are both kept",
-               "frames_per_launch": 644000, "kernels": kernels}, open(out, "w"), indent=1)
-    for k in ("stft_psd_kernel", "peak_pick_kernel<true>"):
+               "frames_per_launch": frames_per_launch, "kernels": kernels}, open(out, "w"), indent=1)
+    for k in ("stft_psd_kernel<float>", "peak_pick32_kernel<2, 4>"):
         if k in kernels:
             print(k, {a: round(b / 1e9, 3) for a, b in kernels[k].items()}, "GB")
 
