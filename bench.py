@@ -424,7 +424,7 @@ def main():
                 "step_achieved": step_alg, "step_frac": step_alg / HBM_PEAK_GBS,
                 "host_overhead_ms_per_step": elapsed / a.steps * 1e3 - sum(v[0] for v in kms.values()) / a.steps,
                 "pipelines": "two halves of the batch run as two passes on two streams (SHZ_DUAL=0: one): kernel durations "
-                             "overlap, their sum exceeds the step and host_overhead goes negative" if os.environ.get("SHZ_DUAL", "1") != "0" else "one",
+                             "overlap, their sum exceeds the step and host_overhead goes negative" if os.environ.get("SHZ_DUAL", "0") not in ("", "0") else "one",
                 "note": "the path is VALU/LDS-bound, not HBM-bound (SURVEY 8d: 30 flop/B fused): frac is small by "
                         "construction; staged_frac is the kernel's own I/O rate"}
 

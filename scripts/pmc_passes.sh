@@ -13,8 +13,7 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_I
 python3 $R/scripts/pmc_counters.py $R/gpurun_out/${TAG}_pmc_counters.json "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras, MI355X" $R/gpurun_out/pmc_a $R/gpurun_out/pmc_b $R/gpurun_out/pmc_c
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_f -o p --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_w -o p --output-format csv -- $B > /dev/null 2>&1
-# (default mode = two pipelines: every launch of the extraction kernels covers half of the 644,000 frames of a step)
-python3 $R/scripts/pmc_traffic.py $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w $R/gpurun_out/${TAG}_pmc_traffic.json "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras, MI355X" ${FRAMES_PER_LAUNCH:-322000}
+python3 $R/scripts/pmc_traffic.py $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w $R/gpurun_out/${TAG}_pmc_traffic.json "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras, MI355X" ${FRAMES_PER_LAUNCH:-644000}
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 cp $R/gpurun_out/prof_stats/p_kernel_stats.csv $R/gpurun_out/${TAG}_bench_kernel_stats.csv
 rm -rf $R/gpurun_out/pmc_? $R/gpurun_out/prof_stats

@@ -73,6 +73,7 @@ struct stft_args {
   const uint32_t* clip_foff;   // [n_clips+1] first frame of each clip (sub-batch numbering)
   uint32_t n_clips;
   uint32_t total_frames;
+  uint32_t frames_per_wg;      // 0: persistent workgroups striding over the frames; k: workgroup b takes frames [k b, k b + k)
   void* out;                   // [total_frames][stride] power (f64, stride DB_STRIDE; or f32, stride P32_STRIDE),
                                // exact zeros stored as 1.0 (= 0 dB)
   const double* window;        // [4096]
@@ -315,10 +316,15 @@ __global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   // XCD-aware frame map: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch), so each
   // group of gridDim/8 workgroups walks ONE contiguous eighth of the frames and the 50 % overlap of
   // neighbouring frames is served by that XCD's L2 (a speed choice only; any placement is correct).
-  const uint32_t gstep = gridDim.x >> 3;                       // host launches a multiple of 8 workgroups
+  uint32_t gstep = gridDim.x >> 3;                             // host launches a multiple of 8 workgroups
   const uint32_t chunk = (a.total_frames + 7) >> 3;
-  const uint32_t g0 = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  const uint32_t gend = min(((blockIdx.x & 7) + 1) * chunk, a.total_frames);
+  uint32_t g0 = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  uint32_t gend = min(((blockIdx.x & 7) + 1) * chunk, a.total_frames);
+  if (a.frames_per_wg) {   // short-lived workgroups: k consecutive frames each, so that CU slots turn over every few dozen
+    gstep = 1;             // microseconds and another stream's small kernels are not held up until this grid ends
+    g0 = min(blockIdx.x * a.frames_per_wg, a.total_frames);
+    gend = min(g0 + a.frames_per_wg, a.total_frames);
+  }
   if (g0 < gend) issue_loads(g0);
 
   for (uint32_t g = g0; g < gend; g += gstep) {
@@ -921,11 +927,12 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.window = ctx->d_window;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
+  a.frames_per_wg = 0;
   return a;
 }
 
 template <typename T>
-static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 0) {
+static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 0, bool persistent = false) {
   shz_prof_scope ps(ctx, 0);
   static const int wgs_per_cu = [] {  // tuning knob: resident stft workgroups per CU (LDS allows 3)
     const char* e = getenv("SHZ_STFT_WGS_PER_CU");
@@ -935,7 +942,16 @@ static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 
   uint32_t grid = (uint32_t)ctx->prop.multiProcessorCount * (wgs_override ? wgs_override : wgs_per_cu);
   if (grid > a.total_frames) grid = a.total_frames;
   grid = (grid + 7) & ~7u;  // multiple of 8: see the XCD-aware frame map in the kernel
-  hipLaunchKernelGGL(stft_psd_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, a);
+  static const uint32_t chunk_frames = [] { const char* e = getenv("SHZ_STFT_CHUNK"); const int v = e ? atoi(e) : 32; return (uint32_t)(v > 0 ? v : 0); }();
+  stft_args b = a;
+  // One pipeline: workgroups of 32 consecutive frames (the halves neighbouring frames share stay in the workgroup's L1,
+  // and CU slots turn over): 4.00 ms per 644,000 frames against 4.35 persistent (4: 4.53, 8: 4.22, 16: 4.05, 64: 4.03).
+  // Two pipelines side by side prefer the persistent grid (6.48 vs 6.55 ms per step).
+  if (!persistent && chunk_frames && a.total_frames > (uint64_t)grid * chunk_frames) {
+    b.frames_per_wg = chunk_frames;
+    grid = (a.total_frames + chunk_frames - 1) / chunk_frames;
+  }
+  hipLaunchKernelGGL(stft_psd_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, b);
   SHZ_HIP(ctx, hipGetLastError());
   return SHZ_OK;
 }
@@ -1102,6 +1118,7 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
 // estimate was too small, or that fp32 staging cannot decide the input (XF_FALLBACK), is repeated with the measured
 // sizes / with fp64 staging.
 struct xparams {
+  bool persistent_stft = false;  // dual pass: persistent STFT grid
   bool f32;                    // fp32 staging + verification (default) or fp64 staging with the exact test in-kernel
   uint32_t peaks_per_frame;    // peak list capacity per frame of a sub-batch
   uint64_t stage_cap;          // host output: capacity of the device staging arrays (entries)
@@ -1216,8 +1233,8 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
     SHZ_TRY(shz_ws_reserve(ctx, par ? SHZ_WS_DB2 : SHZ_WS_DB, (uint64_t)sb.frames * pw_bytes_per_frame, &x.d_pw));
     x.sa = make_stft_args(ctx, x.d_pcm, x.sd, sb.c1 - sb.c0, sb.frames, fs, x.d_pw);
     static const int ov_wgs = [] { const char* e = getenv("SHZ_OVERLAP_STFT_WGS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 3 ? v : 2; }();
-    if (xp.f32) SHZ_TRY(launch_stft<float>(ctx, x.sa, overlap ? ov_wgs : 0));
-    else SHZ_TRY(launch_stft<double>(ctx, x.sa));
+    if (xp.f32) SHZ_TRY(launch_stft<float>(ctx, x.sa, overlap ? ov_wgs : 0, xp.persistent_stft || overlap));
+    else SHZ_TRY(launch_stft<double>(ctx, x.sa, 0, xp.persistent_stft));
     if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_stft[par], ctx->stream2));
     return SHZ_OK;
   };
@@ -1449,8 +1466,11 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
   // Dual pass: the clips are cut in two halves by frames and each half runs as a pass of its own -- the first on this
   // context, the second on a twin context (own stream, own workspace) whose entries are appended behind the first
   // half's afterwards.  Two independent pipelines fill each other's stalls (STFT is VALU/LDS-bound, peak picking waits
-  // on memory): +9-11 % on 1,000 x 30 s clips, which the stage-by-stage pipeline of SHZ_OVERLAP_SPLIT does not reach.
-  static const bool dual_on = [] { const char* e = getenv("SHZ_DUAL"); return !e || atoi(e) != 0; }();
+  // on memory): 7.0 -> 6.48 ms on 1,000 x 30 s clips with the persistent STFT grid, which the stage-by-stage pipeline of
+  // SHZ_OVERLAP_SPLIT does not reach.
+  // Opt-in (SHZ_DUAL=1): with the STFT in short-lived workgroups one pipeline reaches 6.62 ms per 1,000 x 30 s clips and
+  // two reach 6.48-6.50 -- 2 % for twice the workspace and kernel durations that no longer mean one kernel's own time.
+  static const bool dual_on = [] { const char* e = getenv("SHZ_DUAL"); return e && atoi(e) != 0; }();
   if (dual_on && n_clips >= 2 && frames >= 131072) {
     uint32_t hc = 1;
     for (uint64_t f = 0; hc < n_clips - 1; ++hc) {
@@ -1468,6 +1488,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     SHZ_HIP(ctx, hipEventRecord(ctx->ev_twin, ctx->stream));
     SHZ_HIP(ctx, hipStreamWaitEvent(tw->stream, ctx->ev_twin, 0));
     xparams xa = xp, xb = xp;
+    xa.persistent_stft = xb.persistent_stft = true;
     uint64_t fb = 0;
     for (uint32_t c = hc; c < n_clips; ++c) fb += shz_frame_count(clip_off[c + 1] - clip_off[c]);
     xa.stage_cap = std::min<uint64_t>(cap, (frames - fb) * per_frame_out + 4096);

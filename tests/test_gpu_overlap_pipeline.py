@@ -31,8 +31,8 @@ print(h.hexdigest(), ctx.extract_stats()["f64_passes"])
 """
 
 
-def _run(split):
-    env = dict(os.environ, SHZ_OVERLAP_SPLIT=str(split))
+def _run(split, dual=0):
+    env = dict(os.environ, SHZ_OVERLAP_SPLIT=str(split), SHZ_DUAL=str(dual))
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     return out.stdout.strip().split()
@@ -43,3 +43,17 @@ def test_pipelined_pass_equals_sequential_pass():
     for split in (2, 5):
         assert _run(split) == seq, split
     assert seq[1] == "0"
+
+
+def test_dual_pass_equals_single_pass():
+    """SHZ_DUAL=1: the two halves of the batch as two passes on two contexts, entries of the second appended behind the
+    first's -- same hashes, same offsets (the child fingerprints 130 x 30 s = 83,720 frames... below the dual threshold
+    of 131,072 frames, so a second child with 260 clips crosses it)."""
+    child_big = CHILD.replace("n, nc = 30 * 44100, 130", "n, nc = 30 * 44100, 260")
+    outs = []
+    for dual in (0, 1):
+        env = dict(os.environ, SHZ_OVERLAP_SPLIT="0", SHZ_DUAL=str(dual))
+        out = subprocess.run([sys.executable, "-c", child_big % ROOT], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.strip().split())
+    assert outs[0] == outs[1]
