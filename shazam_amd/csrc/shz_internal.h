@@ -69,6 +69,8 @@ enum {
   SHZ_WS_OFFS,       // per-clip output offsets (u64)
   SHZ_WS_UND,        // undecided cells of fp32 peak picking
   SHZ_WS_M0, SHZ_WS_M1, SHZ_WS_M2, SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7,
+  SHZ_WS_M8, SHZ_WS_M9,      // top-n candidates of the vote fold (M3 / M4 hold the probe's group tables until the last vote pass)
+  SHZ_WS_VT0, SHZ_WS_VT1, SHZ_WS_VT2, SHZ_WS_VT3,   // vote tiles: tile starts, candidate records
   SHZ_WS_COUNT
 };
 
@@ -151,7 +153,7 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
 // stable LSD radix sort of 4-byte keys on bits [bit_lo, bit_hi) (k0 <-> k1 ping-pong); the result is written to out64 as
 // 8-byte keys, key + add
 int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
-                           uint64_t add);
+                           uint64_t add, int* sel);
 
 // ---- RCCL helpers (shz_comm.hip) ----------------------------------------------------------
 int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks);

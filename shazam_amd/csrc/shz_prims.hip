@@ -572,12 +572,15 @@ __global__ void widen32_kernel(const uint32_t* __restrict__ in, uint64_t* __rest
   if (i < n) out[i] = (uint64_t)in[i] + add;
 }
 
+// out64 == nullptr: every pass writes 4-byte keys and *sel says which of k0 / k1 holds the result
 int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
-                           uint64_t add) {
+                           uint64_t add, int* sel) {
+  if (sel) *sel = 0;
   if (n == 0) return SHZ_OK;
   if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort: n must be < 2^32 (got %llu)", (unsigned long long)n);
   if (bit_hi > 32) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: bits [%d, %d)", bit_lo, bit_hi);
   if (bit_hi <= bit_lo) {
+    if (!out64) return SHZ_OK;
     hipLaunchKernelGGL(widen32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)k0, out64, n, add);
     SHZ_HIP(ctx, hipGetLastError());
     return SHZ_OK;
@@ -594,7 +597,7 @@ int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* o
     const int w = wide ? (bit_hi - shift + left - 1) / left : 8;
     const int wb = w == 9 ? 9 : 8;
     const uint32_t dmask = (1u << std::min(wb, bit_hi - shift)) - 1u;
-    const bool last = shift + wb >= bit_hi;
+    const bool last = out64 && shift + wb >= bit_hi;
     if (wb == 9) {
       hipLaunchKernelGGL(sort_hist32_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, n, shift, dmask, (uint32_t*)hist, nblocks);
       SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, (uint64_t)nblocks << 9, nullptr));
@@ -610,6 +613,7 @@ int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* o
     shift += wb;
     std::swap(kin, kout);
   }
+  if (sel) *sel = kin == k1 ? 1 : 0;
   return SHZ_OK;
 }
 
@@ -624,7 +628,7 @@ extern "C" int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t 
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &o));
   SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
-  SHZ_TRY(shz_sort_u32_widen(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, (uint64_t*)o, n, (int)bit_lo, (int)bit_hi, add));
+  SHZ_TRY(shz_sort_u32_widen(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, (uint64_t*)o, n, (int)bit_lo, (int)bit_hi, add, nullptr));
   SHZ_HIP(ctx, shz_memcpy(ctx, out64, o, n * 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;

@@ -2106,6 +2106,545 @@ __global__ __launch_bounds__(256) void m_topn_final_kernel(const uint64_t* __res
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Vote tiles: the fold of 4-byte votes without sorting them all the way.
+// A record (best count of one delta, smallest delta reaching it, rows matched) is a function of the MULTISET of a
+// (query, song) group's votes, and the top-n of a query is a function of its records, so the full order the radix
+// sort produced (four passes + run lengths + scans + dense records) is not needed.  Two radix passes order the votes
+// by their upper 16 bits only (query | upper song-id bits); the array is then cut into tiles of ~VT_TILE votes at
+// places where those bits change, never inside a (query, song) group and never across queries; one workgroup per
+// tile counts (song, delta) in an LDS hash table, reduces that to one entry per song in a second table (atomicMax of
+// count << 32 | ~delta, atomicAdd of the flags) and picks the tile's top-n; a last kernel ranks the tiles' candidates
+// of every query.  g_pack (count << 32 | ~sid) is the rank of align_matches as in m_reduce_kernel: count descending,
+// song id ascending, and the delta of a record is the smallest one reaching the count (recognizer.py:305-322 as
+// restated in oracle/match.py).
+#define VT_THREADS 1024
+#define VT_SLOTS 8192          // per LDS table (4 arrays of 4 bytes x VT_SLOTS = 128 KB)
+#define VT_TILE 2048           // votes per tile before the cut is moved to the next group border
+#define VT_LIMIT 6144          // distinct keys a table may hold: VT_TILE + 2^12 deltas of one song always fit one sweep
+#define VT_MAXQ 16             // queries per vote pass
+#define VT_MAXTOPN 8
+#define VT_MAX_DBITS 12
+#define VT_EMPTY 0xFFFFFFFFu
+
+struct vt_plan {
+  uint32_t nq;                 // queries of the pass
+  uint32_t qv[VT_MAXQ + 1];    // first vote of every query in the ordered pass (prefix sums of the per-query counts)
+  uint32_t tb[VT_MAXQ + 1];    // first tile of every query; tb[nq] = number of tiles
+  int g_lo;                    // lowest bit the radix passes ordered: tiles are cut where bits >= g_lo change
+  int dbits, sb;               // layout of a vote: flag | delta (dbits) | song id (sb) | query
+  uint32_t tile;               // nominal votes per tile
+};
+
+__device__ __forceinline__ uint32_t vt_query_of_tile(const vt_plan& pl, uint32_t g) {
+  uint32_t i = 0;
+  while (i + 1 < pl.nq && pl.tb[i + 1] <= g) ++i;   // tb[i] <= g < tb[i + 1]; queries without votes have no tiles
+  return i;
+}
+
+// tile_start[g], g = 0 .. ntiles: the first tile of a query starts at the query's first vote, the others at the first
+// group border at or behind their nominal start (binary search: the votes are ordered by the bits >= g_lo)
+__global__ void vt_bounds_kernel(const uint32_t* __restrict__ k, vt_plan pl, uint32_t* __restrict__ tile_start,
+                                 uint32_t* __restrict__ n_heavy) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, nt = pl.tb[pl.nq];
+  if (g > nt) return;
+  if (g == nt) { tile_start[g] = pl.qv[pl.nq]; *n_heavy = 0; return; }
+  const uint32_t i = vt_query_of_tile(pl, g), l = g - pl.tb[i];
+  const uint32_t a = pl.qv[i], b = pl.qv[i + 1];
+  if (l == 0) { tile_start[g] = a; return; }
+  const uint32_t p = a + l * pl.tile;   // < b: the query has ceil((b - a) / tile) tiles
+  const uint32_t h = k[p - 1] >> pl.g_lo;
+  uint32_t lo = p, hi = b;              // first position in [p, b) whose upper bits exceed h
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if ((k[mid] >> pl.g_lo) > h) hi = mid; else lo = mid + 1;
+  }
+  tile_start[g] = lo;
+}
+
+#define VT_SLOTS2 4096         // table 2 (one entry per song)
+#define VT_LIMIT2 3000         // songs a sweep may hold: VT_LIMIT2 + one row of new ones stays below VT_SLOTS2
+static_assert(VT_SLOTS == 1 << 13 && VT_SLOTS2 == 1 << 12, "vt_hash<13> / vt_hash<12>");
+static_assert(VT_LIMIT + VT_THREADS < VT_SLOTS && VT_LIMIT2 + VT_THREADS < VT_SLOTS2, "a probe must find a free slot");
+static_assert(VT_TILE + (1 << VT_MAX_DBITS) <= VT_LIMIT && VT_TILE < VT_LIMIT2, "the finest sweep always fits");
+
+template <int BITS>
+__device__ __forceinline__ uint32_t vt_hash(uint32_t x) { return (x * 2654435761u) >> (32 - BITS); }
+
+// Slots of N (song | delta) keys in table 1 and of their N songs in table 2, open addressing, inserted if absent.
+// All compare-and-swaps of a round are in flight together: a round costs one LDS round trip, not 2 N.
+template <int N, int B1, int B2>
+__device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const uint32_t (&x1)[N], const uint32_t (&x2)[N],
+                                         const bool (&valid)[N], uint32_t (&s1)[N], uint32_t (&s2)[N], bool (&fresh1)[N],
+                                         bool (&fresh2)[N]) {
+  bool p1[N], p2[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    s1[r] = vt_hash<B1>(x1[r]);
+    s2[r] = vt_hash<B2>(x2[r]);
+    p1[r] = p2[r] = valid[r];
+    fresh1[r] = fresh2[r] = false;
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < N; ++r) any |= p1[r] | p2[r];
+    if (!any) break;
+    uint32_t o1[N], o2[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      o1[r] = p1[r] ? atomicCAS(&key1[s1[r]], VT_EMPTY, x1[r]) : 0u;
+      o2[r] = p2[r] ? atomicCAS(&key2[s2[r]], VT_EMPTY, x2[r]) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      if (p1[r]) {
+        if (o1[r] == VT_EMPTY) { fresh1[r] = true; p1[r] = false; }
+        else if (o1[r] == x1[r]) p1[r] = false;
+        else s1[r] = (s1[r] + 1) & ((1u << B1) - 1u);
+      }
+      if (p2[r]) {
+        if (o2[r] == VT_EMPTY) { fresh2[r] = true; p2[r] = false; }
+        else if (o2[r] == x2[r]) p2[r] = false;
+        else s2[r] = (s2[r] + 1) & ((1u << B2) - 1u);
+      }
+    }
+  }
+}
+
+// N votes of a lane: count of (song, delta) in table 1; the song's entry of table 2 keeps the largest count seen and,
+// among equal counts, the smallest delta (counts only grow, so the maximum over all increments is the maximum of the
+// final counts), and the number of flagged votes.  Songs entered for the first time are appended to lst (length *n2),
+// one LDS atomic per wave; *n1 counts table 1's entries when `count1`.  Called by whole waves.
+template <int N>
+__device__ __forceinline__ void vt_votes(uint32_t* key1, uint32_t* cnt, uint32_t* key2, unsigned long long* best,
+                                         uint32_t* ded, uint16_t* lst, uint32_t* n1, uint32_t* n2, bool count1,
+                                         const uint32_t (&v)[N], const bool (&valid)[N], int dbits, uint32_t dmask) {
+  uint32_t x1[N], x2[N], s1[N], s2[N];
+  bool f1[N], f2[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) { x1[r] = v[r] >> 1; x2[r] = x1[r] >> dbits; }
+  vt_slots<N, 13, 12>(key1, key2, x1, x2, valid, s1, s2, f1, f2);
+  uint32_t c[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) c[r] = valid[r] ? atomicAdd(&cnt[s1[r]], 1u) : 0u;
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+    if (valid[r]) {
+      atomicMax(&best[s2[r]], ((unsigned long long)(c[r] + 1u) << 32) | (dmask - (x1[r] & dmask)));
+      if (v[r] & 1u) atomicAdd(&ded[s2[r]], 1u);
+    }
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long fb[N];
+  uint32_t tot = 0, tot1 = 0;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    fb[r] = __ballot(f2[r]);
+    tot += (uint32_t)__popcll(fb[r]);
+    if (count1) tot1 += (uint32_t)__popcll(__ballot(f1[r]));
+  }
+  if (count1 && tot1 && lane == 0) atomicAdd(n1, tot1);
+  if (tot == 0) return;   // uniform
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(n2, tot);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    if (f2[r]) lst[base + (uint32_t)__popcll(fb[r] & lt)] = (uint16_t)s2[r];
+    base += (uint32_t)__popcll(fb[r]);
+  }
+}
+
+// maximum of v over the wave (all lanes get it): DPP inside the rows of 16 lanes, then the four row results
+__device__ __forceinline__ uint32_t vt_wave_max(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, true));
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+
+#ifdef VT_PROFILE
+__device__ unsigned long long vt_prof[16];
+#define VT_STAMP(i) do { if (j == 0) { const unsigned long long now_ = wall_clock64(); t_acc[i] += now_ - t_last; t_last = now_; } } while (0)
+extern "C" int32_t shz_debug_vt_prof(unsigned long long* out) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vt_prof), sizeof(z)) != hipSuccess) return SHZ_E_HIP;
+  return hipMemcpyToSymbol(HIP_SYMBOL(vt_prof), z, sizeof(z)) == hipSuccess ? SHZ_OK : SHZ_E_HIP;
+}
+#else
+#define VT_STAMP(i)
+#endif
+
+// Persistent workgroups, tile g = blockIdx.x, + gridDim.x, ...  Per tile (and per sweep of an over-full tile):
+//   A  every vote: vt_votes (both tables at once)
+//   C  wave 0: top-n of the listed songs (+ the candidates of earlier sweeps)
+//   D  both tables cleared for the next tile
+// The first VT_ROWS rows of the NEXT tile's votes are requested after A, so that they arrive during C and D.
+#define VT_ROWS 3
+
+__global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __restrict__ k,
+                                                             const uint2* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ n_ranges, uint32_t cap, vt_plan pl,
+                                                             uint32_t topn, uint64_t* __restrict__ c_pack,
+                                                             uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup) {
+  __shared__ uint4 t1[VT_SLOTS / 2];                  // table 1: key1[VT_SLOTS] | cnt[VT_SLOTS]
+  __shared__ uint32_t key2[VT_SLOTS2];
+  __shared__ unsigned long long best[VT_SLOTS2];     // count << 32 | dmask - delta
+  __shared__ uint32_t ded[VT_SLOTS2];
+  __shared__ uint16_t lst[VT_SLOTS2];
+  __shared__ uint64_t s_cpack[2][VT_MAXTOPN];
+  __shared__ uint32_t s_cdelta[2][VT_MAXTOPN], s_cdedup[2][VT_MAXTOPN];
+  __shared__ uint32_t s_n1, s_n2;
+  uint32_t* const key1 = (uint32_t*)t1;
+  uint32_t* const cnt = key1 + VT_SLOTS;
+  const uint32_t j = threadIdx.x, lane = j & 63, nt = min(*n_ranges, cap);
+  if (blockIdx.x >= nt) return;   // the usual case: nothing was handed over
+#ifdef VT_PROFILE
+  unsigned long long t_last = wall_clock64(), t_acc[8] = {0};
+#endif
+  const uint32_t dmask = (1u << pl.dbits) - 1u, smask = (pl.sb >= 32 ? ~0u : (1u << pl.sb) - 1u);
+  const int slb = pl.g_lo - 1 - pl.dbits;           // song-id bits below the ordered ones: what sweeps may split by
+  auto clear1 = [&]() {
+    for (uint32_t i = j; i < VT_SLOTS / 4; i += VT_THREADS) t1[i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
+    for (uint32_t i = VT_SLOTS / 4 + j; i < VT_SLOTS / 2; i += VT_THREADS) t1[i] = make_uint4(0, 0, 0, 0);
+  };
+  clear1();
+  for (uint32_t i = j; i < VT_SLOTS2; i += VT_THREADS) { key2[i] = VT_EMPTY; best[i] = 0; ded[i] = 0; }
+  if (j == 0) { s_n1 = 0; s_n2 = 0; }
+  uint32_t g = blockIdx.x;
+  uint32_t a = 0, b = 0, pre[VT_ROWS];
+  if (g < nt) { a = ranges[g].x; b = ranges[g].y; }
+#pragma unroll
+  for (int r = 0; r < VT_ROWS; ++r) { const uint32_t i = a + r * VT_THREADS + j; pre[r] = i < b ? k[i] : 0u; }
+  __syncthreads();
+  for (; g < nt; g += gridDim.x) {
+    const uint32_t gn = g + gridDim.x;
+    uint32_t na = 0, nb = 0;                         // (both 0 behind the last tile: nothing is loaded)
+    if (gn < nt) { na = ranges[gn].x; nb = ranges[gn].y; }
+    const bool checked = b - a > VT_LIMIT2;         // fewer votes than either table may hold: no sweep can overflow
+    int cl = 0, nsl = 0;                             // candidate list in use, log2 of the number of sweeps
+    bool prefetched = false;
+    VT_STAMP(0);
+    for (bool done = (a >= b); !done;) {             // until a sweep count is found under which every sweep fits
+      bool over = false;
+      cl = 0;
+      for (uint32_t sw = 0; sw < (1u << nsl) && !over; ++sw) {
+        // ---- A
+        if (!checked && nsl == 0 && b - a <= VT_ROWS * VT_THREADS) {   // the usual tile: its rows are in registers
+          bool ok[VT_ROWS];
+#pragma unroll
+          for (int r = 0; r < VT_ROWS; ++r) ok[r] = a + r * VT_THREADS + j < b;
+          vt_votes<VT_ROWS>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, false, pre, ok, pl.dbits, dmask);
+        } else {
+          for (uint32_t row = 0, base = a; base < b; base += VT_THREADS, ++row) {
+            const uint32_t i = base + j;
+            uint32_t v[1] = {0};
+            if (row < VT_ROWS && nsl == 0) v[0] = row == 0 ? pre[0] : row == 1 ? pre[1] : pre[2];
+            else if (i < b) v[0] = k[i];
+            const uint32_t x = v[0] >> 1;
+            const bool ok[1] = {i < b && (nsl == 0 || (((x >> pl.dbits) & ((1u << slb) - 1u)) >> (slb - nsl)) == sw)};
+            vt_votes<1>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, true, v, ok, pl.dbits, dmask);
+            if (checked) {
+              __syncthreads();
+              over = s_n1 > VT_LIMIT || s_n2 > VT_LIMIT2;      // uniform: read between two barriers
+              __syncthreads();
+              if (over) break;
+            }
+          }
+        }
+        static_assert(VT_ROWS == 3, "the row select above names pre[0..2]");
+        __syncthreads();
+        VT_STAMP(1);
+        const uint32_t n2 = s_n2;
+        if (!prefetched) {               // the next tile's first rows: in flight during C and D
+          prefetched = true;
+#pragma unroll
+          for (int r = 0; r < VT_ROWS; ++r) { const uint32_t i = na + r * VT_THREADS + j; pre[r] = i < nb ? k[i] : 0u; }
+        }
+        // ---- C: rank = (count descending, song id ascending); the smallest delta reaching the count is in best
+        if (j < 64 && !over) {
+          constexpr int CE = 12;                     // songs per lane whose rank stays in registers (n2 <= 768: the usual tile)
+          uint64_t cpk[CE];
+          const bool cached = n2 <= 64 * CE;         // uniform
+          if (cached) {
+            uint32_t cs[CE];
+#pragma unroll
+            for (int u = 0; u < CE; ++u) { const uint32_t e = lane + 64 * u; cs[u] = e < n2 ? lst[e] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int u = 0; u < CE; ++u)
+              cpk[u] = cs[u] == 0xFFFFFFFFu ? 0ull : ((best[cs[u]] >> 32) << 32) | (0xFFFFFFFFu - (key2[cs[u]] & smask));
+          }
+          uint64_t prev = ~0ull;
+          const uint64_t old = (sw > 0 && lane < topn) ? s_cpack[cl][lane] : 0ull;
+          for (uint32_t n = 0; n < topn; ++n) {
+            uint64_t m = old < prev ? old : 0ull;
+            uint32_t ms = 0xFFFFFFFFu;               // slot of m (0xFFFFFFFF: the old candidate), index of the entry if cached
+            if (cached) {
+#pragma unroll
+              for (int u = 0; u < CE; ++u)
+                if (cpk[u] < prev && cpk[u] > m) { m = cpk[u]; ms = lane + 64 * u; }
+            } else {
+              for (uint32_t e = lane; e < n2; e += 64) {
+                const uint32_t s = lst[e];
+                const uint64_t pk = ((best[s] >> 32) << 32) | (0xFFFFFFFFu - (key2[s] & smask));
+                if (pk < prev && pk > m) { m = pk; ms = s; }
+              }
+            }
+            const uint32_t cmax = vt_wave_max((uint32_t)(m >> 32));
+            const uint32_t lo = vt_wave_max((uint32_t)(m >> 32) == cmax ? (uint32_t)m : 0u);
+            const uint64_t w = ((uint64_t)cmax << 32) | lo;     // the wave's best below prev (0: none left)
+            if (w != 0 && m == w) {                              // one lane: packs are unique
+              if (cached && ms != 0xFFFFFFFFu) ms = lst[ms];
+              s_cpack[cl ^ 1][n] = w;
+              s_cdelta[cl ^ 1][n] = ms == 0xFFFFFFFFu ? s_cdelta[cl][lane] : dmask - ((uint32_t)best[ms] & dmask);
+              s_cdedup[cl ^ 1][n] = ms == 0xFFFFFFFFu ? s_cdedup[cl][lane] : ded[ms];
+            }
+            if (w == 0 && lane == 0) { s_cpack[cl ^ 1][n] = 0; s_cdelta[cl ^ 1][n] = 0; s_cdedup[cl ^ 1][n] = 0; }
+            prev = w;   // 0 once exhausted: nothing ranks below it
+          }
+        }
+        __syncthreads();
+        VT_STAMP(2);
+        // ---- D (also what an overflowing sweep leaves behind)
+        clear1();
+        for (uint32_t e = j; e < n2; e += VT_THREADS) { const uint32_t s = lst[e]; key2[s] = VT_EMPTY; best[s] = 0; ded[s] = 0; }
+        if (j == 0) { s_n1 = 0; s_n2 = 0; }
+        if (!over) cl ^= 1;
+        __syncthreads();
+        VT_STAMP(3);
+      }
+      if (!over) { done = true; break; }
+      // at nsl == slb a sweep is one song of the last group (<= 2^VT_MAX_DBITS deltas) + less than VT_TILE other votes,
+      // which fits; the host does not choose this path for wider deltas.  (The test only keeps a wrong call from hanging.)
+      if (nsl >= slb) { if (j < VT_MAXTOPN) s_cpack[0][j] = 0; cl = 0; done = true; }
+      ++nsl;
+      __syncthreads();
+    }
+    if (!prefetched) {   // an empty tile, or one given up
+#pragma unroll
+      for (int r = 0; r < VT_ROWS; ++r) { const uint32_t i = na + r * VT_THREADS + j; pre[r] = i < nb ? k[i] : 0u; }
+    }
+    if (j < topn) {
+      const uint64_t o = (uint64_t)g * topn + j;
+      const bool any = a < b;
+      c_pack[o] = any ? s_cpack[cl][j] : 0ull;
+      c_delta[o] = any ? s_cdelta[cl][j] : 0u;
+      c_dedup[o] = any ? s_cdedup[cl][j] : 0u;
+    }
+    __syncthreads();   // the candidate lists are rewritten by the next tile
+    VT_STAMP(4);
+#ifdef VT_PROFILE
+    if (j == 0) t_acc[7] += 1;
+#endif
+    a = na;
+    b = nb;
+  }
+#ifdef VT_PROFILE
+  if (j == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&vt_prof[i], t_acc[i]);
+#endif
+}
+
+// ---- the usual path: one WAVE per tile of ~VW_CHUNK votes, streaming through it with wave-private tables.
+// No barriers, no LDS counters: a CU runs nine such waves side by side, each hiding the others' LDS round trips.
+// The wave adds whole groups (votes that share the ordered bits) to its tables until VW_FLUSH votes are in, and at
+// the next group border merges the songs of that batch into its running top-n (lane n holds candidate n) and clears
+// the tables.  A batch whose distinct (song, delta) pairs or songs outgrow the tables -- one group with hundreds of
+// pairs: copies of one recording, stationary tones -- is handed to vt_fold_kernel as the range [batch start, next
+// group border): at most VW_FLUSH + 64 votes in front of its last group, so that kernel's bound holds for it too.
+#define VW_B1 9
+#define VW_B2 8
+#define VW_S1 (1 << VW_B1)     // (song | delta) entries of a batch
+#define VW_S2 (1 << VW_B2)     // songs of a batch
+#define VW_LIMIT1 384
+#define VW_LIMIT2 176
+#define VW_FLUSH 64
+#define VW_CHUNK 2048
+#define VW_HEAVY_PER_TILE 16   // every range has more than VW_LIMIT2 votes: at most 10 inside the nominal tile + the one around its last group
+static_assert(VW_LIMIT1 + 64 < VW_S1 && VW_LIMIT2 + 64 < VW_S2, "a probe must find a free slot");
+static_assert(VW_FLUSH + 64 <= VT_TILE, "a range handed to vt_fold_kernel has less than VT_TILE votes before its last group");
+
+__global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restrict__ k, const uint32_t* __restrict__ tile_start,
+                                                       vt_plan pl, uint32_t topn, uint64_t* __restrict__ c_pack,
+                                                       uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
+                                                       uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
+                                                       uint32_t* __restrict__ heavy_q, uint32_t heavy_cap) {
+  __shared__ uint4 t1[VW_S1 / 2];                    // key1[VW_S1] | cnt[VW_S1]
+  __shared__ uint4 t2[VW_S2];                        // key2[VW_S2] | ded[VW_S2] | best[VW_S2] (8 bytes each)
+  uint32_t* const key1 = (uint32_t*)t1;
+  uint32_t* const cnt = key1 + VW_S1;
+  uint32_t* const key2 = (uint32_t*)t2;
+  uint32_t* const ded = key2 + VW_S2;
+  unsigned long long* const best = (unsigned long long*)(ded + VW_S2);
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  const uint32_t a = tile_start[g], b = tile_start[g + 1];
+  const uint32_t dmask = (1u << pl.dbits) - 1u, smask = (pl.sb >= 32 ? ~0u : (1u << pl.sb) - 1u);
+  uint64_t cp = 0;                                   // lane n < topn: candidate n of this tile
+  uint32_t cdl = 0, cdd = 0;
+  auto clear = [&]() {
+#pragma unroll
+    for (int i = 0; i < VW_S1 / 4 / 64; ++i) t1[lane + 64 * i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
+#pragma unroll
+    for (int i = 0; i < VW_S1 / 4 / 64; ++i) t1[VW_S1 / 4 + lane + 64 * i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < VW_S2 / 4 / 64; ++i) t2[lane + 64 * i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
+#pragma unroll
+    for (int i = VW_S2 / 4 / 64; i < VW_S2 / 64; ++i) t2[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+  };
+  if (a < b) {
+    clear();
+    uint32_t n1 = 0, n2 = 0, batch_start = a, batch_votes = 0, last_hi = 0xFFFFFFFFu;   // wave-uniform
+    bool skip = false;                               // the current batch goes to vt_fold_kernel: look for its end
+    auto insert = [&](bool act, uint32_t v) {        // whole wave
+      const uint32_t x1[1] = {v >> 1}, x2[1] = {(v >> 1) >> pl.dbits};
+      uint32_t s1[1], s2[1];
+      bool f1[1], f2[1];
+      const bool ok[1] = {act};
+      vt_slots<1, VW_B1, VW_B2>(key1, key2, x1, x2, ok, s1, s2, f1, f2);
+      if (act) {
+        const uint32_t c = atomicAdd(&cnt[s1[0]], 1u);
+        atomicMax(&best[s2[0]], ((unsigned long long)(c + 1u) << 32) | (dmask - (x1[0] & dmask)));
+        if (v & 1u) atomicAdd(&ded[s2[0]], 1u);
+      }
+      n2 += (uint32_t)__popcll(__ballot(f2[0]));
+      n1 += (uint32_t)__popcll(__ballot(f1[0]));
+      batch_votes += (uint32_t)__popcll(__ballot(act));
+    };
+    auto flush = [&]() {                             // the batch's songs into the running top-n; tables emptied
+      if (n2 != 0) {
+        constexpr int CE = VW_S2 / 64;               // every slot of table 2: CE per lane
+        uint64_t pk[CE];
+#pragma unroll
+        for (int u = 0; u < CE; ++u) {
+          const uint32_t s = lane + 64 * u, kk = key2[s];
+          pk[u] = kk == VT_EMPTY ? 0ull : ((best[s] >> 32) << 32) | (0xFFFFFFFFu - (kk & smask));
+        }
+        uint64_t prev = ~0ull, ncp = 0;
+        uint32_t ncdl = 0, ncdd = 0;
+        for (uint32_t n = 0; n < topn; ++n) {
+          uint64_t m = cp < prev ? cp : 0ull;        // (lanes >= topn hold 0)
+          int mu = -1;                               // entry of m, -1: the old candidate
+#pragma unroll
+          for (int u = 0; u < CE; ++u)
+            if (pk[u] < prev && pk[u] > m) { m = pk[u]; mu = u; }
+          const uint32_t cmax = vt_wave_max((uint32_t)(m >> 32));
+          const uint32_t lo = vt_wave_max((uint32_t)(m >> 32) == cmax ? (uint32_t)m : 0u);
+          const uint64_t w = ((uint64_t)cmax << 32) | lo;
+          if (w == 0) break;                         // uniform: nothing ranks below prev
+          const int win = __ffsll((long long)__ballot(m == w)) - 1;   // one lane: packs are unique
+          uint32_t wdl = cdl, wdd = cdd;
+          if ((int)lane == win && mu >= 0) { const uint32_t s = lane + 64 * mu; wdl = dmask - ((uint32_t)best[s] & dmask); wdd = ded[s]; }
+          wdl = (uint32_t)__shfl((int)wdl, win, 64);
+          wdd = (uint32_t)__shfl((int)wdd, win, 64);
+          if (lane == n) { ncp = w; ncdl = wdl; ncdd = wdd; }
+          prev = w;
+        }
+        cp = ncp; cdl = ncdl; cdd = ncdd;
+      }
+      clear();
+      n1 = n2 = 0;
+    };
+    auto hand_over = [&](uint32_t e) {               // [batch_start, e) to vt_fold_kernel
+      if (lane == 0) {
+        const uint32_t idx = atomicAdd(n_heavy, 1u);
+        if (idx < heavy_cap) { heavy[idx] = make_uint2(batch_start, e); heavy_q[idx] = vt_query_of_tile(pl, g); }
+      }
+    };
+    uint32_t r0, r1, r2, r3;                         // the next four rows of votes: loads in flight
+    { uint32_t i = a + lane; r0 = i < b ? k[i] : 0u; i += 64; r1 = i < b ? k[i] : 0u; i += 64; r2 = i < b ? k[i] : 0u; i += 64; r3 = i < b ? k[i] : 0u; }
+    for (uint32_t base = a; base < b; base += 64) {
+      const uint32_t v = r0;
+      r0 = r1; r1 = r2; r2 = r3;
+      { const uint32_t i = base + 256 + lane; r3 = i < b ? k[i] : 0u; }
+      const bool valid = base + lane < b;
+      const uint32_t hi = v >> pl.g_lo;
+      uint32_t hp = (uint32_t)__shfl_up((int)hi, 1, 64);
+      if (lane == 0) hp = last_hi;
+      const unsigned long long mg = __ballot(valid && hi != hp);     // lanes that open a group
+      last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);    // (the last row is the only partial one)
+      uint32_t lo = 0;                               // first lane of the row not dealt with yet
+      while (lo < 64) {                              // uniform
+        const unsigned long long rest = mg & ~((1ull << lo) - 1ull);
+        if (skip) {
+          if (!rest) break;
+          lo = (uint32_t)__ffsll((long long)rest) - 1;
+          hand_over(base + lo);
+          skip = false;
+          batch_start = base + lo;
+          batch_votes = 0;
+          continue;
+        }
+        uint32_t cut = 64;                           // the batch may end at the next group border once it is large enough
+        if (batch_votes >= VW_FLUSH && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
+        if (cut == lo) { flush(); batch_start = base + lo; batch_votes = 0; continue; }
+        insert(valid && lane >= lo && lane < cut, v);
+        const bool over = n1 > VW_LIMIT1 || n2 > VW_LIMIT2;
+        if (over) {
+          clear();
+          n1 = n2 = 0;
+          if (cut < 64) { hand_over(base + cut); batch_start = base + cut; batch_votes = 0; }
+          else skip = true;
+        } else if (cut < 64) { flush(); batch_start = base + cut; batch_votes = 0; }
+        lo = cut;
+      }
+    }
+    if (skip) hand_over(b); else flush();
+  }
+  if (lane < topn) {
+    const uint64_t o = (uint64_t)g * topn + lane;
+    c_pack[o] = cp;
+    c_delta[o] = cdl;
+    c_dedup[o] = cdd;
+  }
+}
+
+// one workgroup per query of the pass: top-n of its tiles' candidates
+__global__ __launch_bounds__(256) void vt_rank_kernel(vt_plan pl, uint32_t topn, m_bits mb, const uint64_t* __restrict__ c_pack,
+                                                      const uint32_t* __restrict__ c_delta,
+                                                      const uint32_t* __restrict__ c_dedup,
+                                                      const uint32_t* __restrict__ n_heavy,
+                                                      const uint32_t* __restrict__ heavy_q, uint32_t heavy_cap,
+                                                      uint32_t* __restrict__ out_sid,
+                                                      int32_t* __restrict__ out_delta, uint32_t* __restrict__ out_aligned,
+                                                      uint32_t* __restrict__ out_dedup, uint32_t* __restrict__ out_nres) {
+  __shared__ uint64_t s_best[4];
+  __shared__ uint32_t s_r[4];
+  const uint32_t q = blockIdx.x;
+  const uint32_t c0 = pl.tb[q] * topn, c1 = pl.tb[q + 1] * topn;
+  const uint32_t nt = pl.tb[pl.nq], nh = min(*n_heavy, heavy_cap);   // candidates of range r: slots (nt + r) * topn ...
+  uint64_t prev = ~0ull;
+  uint32_t found = 0;
+  for (uint32_t n = 0; n < topn; ++n) {
+    uint64_t best = 0;
+    uint32_t bestr = 0xFFFFFFFFu;
+    for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
+      const uint64_t packed = c_pack[i];
+      if (packed < prev && packed > best) { best = packed; bestr = i; }
+    }
+    for (uint32_t i = threadIdx.x; i < nh * topn; i += 256) {
+      if (heavy_q[i / topn] != q) continue;
+      const uint64_t packed = c_pack[(uint64_t)nt * topn + i];
+      if (packed < prev && packed > best) { best = packed; bestr = nt * topn + i; }
+    }
+    topn_block_max(best, bestr, s_best, s_r);
+    if (best == 0) break;  // uniform
+    if (threadIdx.x == 0) {
+      const uint64_t o = (uint64_t)q * topn + n;
+      out_sid[o] = 0xFFFFFFFFu - (uint32_t)best;
+      out_aligned[o] = (uint32_t)(best >> 32);
+      out_delta[o] = (int32_t)((int64_t)c_delta[bestr] - (int64_t)mb.bias);
+      out_dedup[o] = c_dedup[bestr];
+    }
+    prev = best;
+    ++found;
+  }
+  if (threadIdx.x == 0) out_nres[q] = found;
+}
+
 // shz_match_pairs: the packed votes themselves leave match_core (device buffer of `cap` entries), in a key layout
 // the caller chose for ALL shards: ((q << sb | sid) << dbits | delta + bias) << 1 | first-offset flag, q global
 struct pair_sink {
@@ -2168,8 +2707,8 @@ static int32_t vote_fold(shz_ctx* ctx, const uint64_t* vs, uint64_t P, uint32_t 
   } else {
     void *pp, *pr;
     const uint64_t ncand = (uint64_t)C * topn;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, (uint64_t)nq * ncand * 8, &pp));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, (uint64_t)nq * ncand * 4, &pr));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M8, (uint64_t)nq * ncand * 8, &pp));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M9, (uint64_t)nq * ncand * 4, &pr));
     hipLaunchKernelGGL(m_topn_partial_kernel, dim3(C, nq), dim3(256), 0, ctx->stream, (const uint32_t*)qstart, d_G, nq,
                        (const uint64_t*)gh, topn, (uint64_t*)pp, (uint32_t*)pr);
     hipLaunchKernelGGL(m_topn_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const uint64_t*)pp, (const uint32_t*)pr,
@@ -2416,12 +2955,16 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       const int qbits32 = 31 - mb.sb - mb.dbits;
       static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
       bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0;
+      // vote tiles (vt_fold_kernel): two radix passes + an LDS fold per tile instead of four passes + the record chain
+      static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
+      const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS;
       if (use32) {
+        const uint32_t q_per_pass = tiles ? std::min<uint32_t>(1u << std::min(qbits32, 30), VT_MAXQ) : (1u << std::min(qbits32, 30));
         uint64_t v = 0;
         for (uint32_t qa = 0; qa < nq;) {
           uint32_t qb = qa;
           uint64_t pv = 0;
-          while (qb < nq && (qb - qa) < (1u << qbits32) && (qb == qa || pv + h_votes[qb] <= P_BUDGET)) pv += h_votes[qb++];
+          while (qb < nq && (qb - qa) < q_per_pass && (qb == qa || pv + h_votes[qb] <= P_BUDGET)) pv += h_votes[qb++];
           if (pv) passes.push_back(vpass{qa, qb, v, v + pv});
           v += pv;
           qa = qb;
@@ -2451,8 +2994,51 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                              (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
                              (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp, -(int64_t)vp.qa, k32);
           SHZ_HIP(ctx, hipGetLastError());
-          SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, (uint64_t*)v1, pp, 1, mbp.qb + mbp.sb + mbp.dbits + 1, 0));
-          SHZ_TRY(vote_fold(ctx, (const uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
+          const int B = mbp.qb + mbp.sb + mbp.dbits + 1;
+          if (tiles) {
+            vt_plan pl;
+            pl.nq = nqp;
+            pl.dbits = mbp.dbits;
+            pl.sb = mbp.sb;
+            pl.g_lo = std::max(1 + mbp.dbits, B - 16);
+            pl.tile = VW_CHUNK;
+            pl.qv[0] = pl.tb[0] = 0;
+            for (uint32_t i = 0; i < nqp; ++i) {
+              const uint64_t c = nq > 1 ? h_votes[vp.qa + i] : pp;
+              pl.qv[i + 1] = pl.qv[i] + (uint32_t)c;
+              pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + VW_CHUNK - 1) / VW_CHUNK);
+            }
+            for (uint32_t i = nqp; i < VT_MAXQ; ++i) { pl.qv[i + 1] = pl.qv[nqp]; pl.tb[i + 1] = pl.tb[nqp]; }
+            const uint32_t nt = pl.tb[nqp], hcap = nt * VW_HEAVY_PER_TILE;
+            int sel = 0;
+            SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, nullptr, pp, pl.g_lo, B, 0, &sel));
+            const uint32_t* ks = sel ? k32 + pmax : k32;
+            // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
+            void *ts, *cp, *cd, *cdd;
+            const uint64_t ncand = ((uint64_t)nt + hcap) * topn;
+            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, ((uint64_t)nt + 4 + (uint64_t)hcap * 3) * 4, &ts));
+            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT1, ncand * 8, &cp));
+            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT2, ncand * 4, &cd));
+            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT3, ncand * 4, &cdd));
+            uint32_t* tile_start = (uint32_t*)ts;
+            uint32_t* n_heavy = tile_start + nt + 1;
+            uint2* heavy = (uint2*)(tile_start + ((nt + 2 + 1) & ~1u));   // 8-byte aligned
+            uint32_t* heavy_q = (uint32_t*)(heavy + hcap);
+            hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)nt + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start, n_heavy);
+            hipLaunchKernelGGL(vt_stream_kernel, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                               (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
+            hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
+                               dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
+                               (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
+                               (uint32_t*)cdd + (uint64_t)nt * topn);
+            hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(256), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
+                               (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, hcap,
+                               rs, rdl, ra, rd, r_n + vp.qa);
+            SHZ_HIP(ctx, hipGetLastError());
+          } else {
+            SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, (uint64_t*)v1, pp, 1, B, 0, nullptr));
+            SHZ_TRY(vote_fold(ctx, (const uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
+          }
         } else {
           hipLaunchKernelGGL(m_expand_kernel<uint64_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                              (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
