@@ -71,6 +71,7 @@ enum {
   SHZ_WS_M0, SHZ_WS_M1, SHZ_WS_M2, SHZ_WS_M3, SHZ_WS_M4, SHZ_WS_M5, SHZ_WS_M6, SHZ_WS_M7,
   SHZ_WS_M8, SHZ_WS_M9,      // top-n candidates of the vote fold (M3 / M4 hold the probe's group tables until the last vote pass)
   SHZ_WS_VT0, SHZ_WS_VT1, SHZ_WS_VT2, SHZ_WS_VT3,   // vote tiles: tile starts, candidate records
+  SHZ_WS_VT4,        // table of the vote passes
   SHZ_WS_COUNT
 };
 

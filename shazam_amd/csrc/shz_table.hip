@@ -1609,6 +1609,27 @@ __global__ void m_tile_start_kernel(const uint64_t* __restrict__ po, uint32_t nx
   tile_x[t] = l;
 }
 
+// the same for EVERY vote pass of a sub-batch in one launch: pass p covers the votes [pv[2p], pv[2p+1]) and owns the
+// entries [toff[p], toff[p+1]) of tile_x (its tiles + 1)
+__global__ void m_tile_start_all_kernel(const uint64_t* __restrict__ po, uint32_t nx, const uint64_t* __restrict__ pv,
+                                        const uint32_t* __restrict__ toff, uint32_t n_pass, uint32_t* __restrict__ tile_x) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= toff[n_pass]) return;
+  uint32_t lo = 0, hi = n_pass;   // last pass with toff[p] <= e
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (toff[mid] <= e) lo = mid; else hi = mid;
+  }
+  const uint64_t v_lo = pv[2 * lo], P = pv[2 * lo + 1];
+  const uint64_t p = min(v_lo + (uint64_t)(e - toff[lo]) * M_EXP_TILE, P - 1);
+  uint32_t l = 0, h = nx;
+  while (h - l > 1) {
+    const uint32_t mid = l + ((h - l) >> 1);
+    if (po[mid] <= p) l = mid; else h = mid;
+  }
+  tile_x[e] = l;
+}
+
 __device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t off, uint32_t first, m_bits mb, int64_t q_base) {
   const uint64_t q = (uint64_t)((int64_t)(e >> QIDX_SHIFT) + q_base);
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
@@ -2603,46 +2624,67 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
 }
 
 // one workgroup per query of the pass: top-n of its tiles' candidates
-__global__ __launch_bounds__(256) void vt_rank_kernel(vt_plan pl, uint32_t topn, m_bits mb, const uint64_t* __restrict__ c_pack,
-                                                      const uint32_t* __restrict__ c_delta,
-                                                      const uint32_t* __restrict__ c_dedup,
-                                                      const uint32_t* __restrict__ n_heavy,
-                                                      const uint32_t* __restrict__ heavy_q, uint32_t heavy_cap,
-                                                      uint32_t* __restrict__ out_sid,
-                                                      int32_t* __restrict__ out_delta, uint32_t* __restrict__ out_aligned,
-                                                      uint32_t* __restrict__ out_dedup, uint32_t* __restrict__ out_nres) {
-  __shared__ uint64_t s_best[4];
-  __shared__ uint32_t s_r[4];
-  const uint32_t q = blockIdx.x;
-  const uint32_t c0 = pl.tb[q] * topn, c1 = pl.tb[q + 1] * topn;
-  const uint32_t nt = pl.tb[pl.nq], nh = min(*n_heavy, heavy_cap);   // candidates of range r: slots (nt + r) * topn ...
+#define VR_THREADS 1024
+#define VR_CACHE 12            // candidates a thread keeps in registers: 12,288 per query before it re-reads them
+
+__global__ __launch_bounds__(VR_THREADS) void vt_rank_kernel(vt_plan pl, uint32_t topn, m_bits mb, const uint64_t* __restrict__ c_pack,
+                                                             const uint32_t* __restrict__ c_delta,
+                                                             const uint32_t* __restrict__ c_dedup,
+                                                             const uint32_t* __restrict__ n_heavy,
+                                                             const uint32_t* __restrict__ heavy_q, uint32_t heavy_cap,
+                                                             uint32_t* __restrict__ out_sid,
+                                                             int32_t* __restrict__ out_delta, uint32_t* __restrict__ out_aligned,
+                                                             uint32_t* __restrict__ out_dedup, uint32_t* __restrict__ out_nres) {
+  __shared__ uint64_t s_best[2][VR_THREADS / 64];
+  const uint32_t q = blockIdx.x, j = threadIdx.x;
+  const uint32_t c0 = pl.tb[q] * topn, nc = (pl.tb[q + 1] - pl.tb[q]) * topn;
+  const uint32_t nt = pl.tb[pl.nq], nh = min(*n_heavy, heavy_cap) * topn;   // candidates of range r: slots (nt + r) * topn ...
+  const bool cached = nc <= VR_CACHE * VR_THREADS;   // uniform
+  uint64_t ck[VR_CACHE];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < VR_CACHE; ++u) { const uint32_t i = j + u * VR_THREADS; ck[u] = i < nc ? c_pack[c0 + i] : 0ull; }
+  }
   uint64_t prev = ~0ull;
   uint32_t found = 0;
   for (uint32_t n = 0; n < topn; ++n) {
     uint64_t best = 0;
     uint32_t bestr = 0xFFFFFFFFu;
-    for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
-      const uint64_t packed = c_pack[i];
-      if (packed < prev && packed > best) { best = packed; bestr = i; }
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < VR_CACHE; ++u)
+        if (ck[u] < prev && ck[u] > best) { best = ck[u]; bestr = c0 + j + u * VR_THREADS; }
+    } else {
+      for (uint32_t i = j; i < nc; i += VR_THREADS) {
+        const uint64_t packed = c_pack[c0 + i];
+        if (packed < prev && packed > best) { best = packed; bestr = c0 + i; }
+      }
     }
-    for (uint32_t i = threadIdx.x; i < nh * topn; i += 256) {
+    for (uint32_t i = j; i < nh; i += VR_THREADS) {    // (usually none)
       if (heavy_q[i / topn] != q) continue;
       const uint64_t packed = c_pack[(uint64_t)nt * topn + i];
       if (packed < prev && packed > best) { best = packed; bestr = nt * topn + i; }
     }
-    topn_block_max(best, bestr, s_best, s_r);
-    if (best == 0) break;  // uniform
-    if (threadIdx.x == 0) {
+    // the block's best: count first, then the low word, inside the waves; the 16 wave results through LDS
+    const uint32_t cmax = vt_wave_max((uint32_t)(best >> 32));
+    const uint32_t lo = vt_wave_max((uint32_t)(best >> 32) == cmax ? (uint32_t)best : 0u);
+    if ((j & 63) == 0) s_best[n & 1][j >> 6] = ((uint64_t)cmax << 32) | lo;
+    __syncthreads();
+    uint64_t w = 0;
+#pragma unroll
+    for (int i = 0; i < VR_THREADS / 64; ++i) w = s_best[n & 1][i] > w ? s_best[n & 1][i] : w;
+    if (w == 0) break;  // uniform
+    if (best == w) {    // one thread: packs are unique
       const uint64_t o = (uint64_t)q * topn + n;
-      out_sid[o] = 0xFFFFFFFFu - (uint32_t)best;
-      out_aligned[o] = (uint32_t)(best >> 32);
+      out_sid[o] = 0xFFFFFFFFu - (uint32_t)w;
+      out_aligned[o] = (uint32_t)(w >> 32);
       out_delta[o] = (int32_t)((int64_t)c_delta[bestr] - (int64_t)mb.bias);
       out_dedup[o] = c_dedup[bestr];
     }
-    prev = best;
+    prev = w;
     ++found;
   }
-  if (threadIdx.x == 0) out_nres[q] = found;
+  if (j == 0) out_nres[q] = found;
 }
 
 // shz_match_pairs: the packed votes themselves leave match_core (device buffer of `cap` entries), in a key layout
@@ -2977,15 +3019,33 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       void *v0, *v1;   // E lives in one of SORT_A/B; the vote buffers use SORT_C/D
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, pmax * 8, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, pmax * 8, &v1));
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, ((pmax + M_EXP_TILE - 1) / M_EXP_TILE + 1) * 4, &tile_x));   // (M5 belongs to the fold)
+      // the sub-group of every expand tile's first pair, for all passes in one launch: pass table (votes, first entry)
+      // up, one kernel
+      std::vector<uint32_t> toff(passes.size() + 1, 0);
+      std::vector<uint64_t> ptab(passes.size() * 2 + (passes.size() + 2) / 2);   // pv[2 n_pass] | toff[n_pass + 1] (u32)
+      for (size_t i = 0; i < passes.size(); ++i) {
+        ptab[2 * i] = passes[i].v_lo;
+        ptab[2 * i + 1] = passes[i].v_hi;
+        toff[i + 1] = toff[i] + (uint32_t)((passes[i].v_hi - passes[i].v_lo + M_EXP_TILE - 1) / M_EXP_TILE) + 1;
+      }
+      memcpy(ptab.data() + passes.size() * 2, toff.data(), toff.size() * 4);
+      void* d_ptab;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT4, ptab.size() * 8, &d_ptab));
+      SHZ_HIP(ctx, shz_memcpy(ctx, d_ptab, ptab.data(), ptab.size() * 8, hipMemcpyHostToDevice));
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)toff.back() * 4, &tile_x));   // (M5 belongs to the fold)
+      hipLaunchKernelGGL(m_tile_start_all_kernel, dim3(nblk(toff.back())), dim3(256), 0, ctx->stream, (const uint64_t*)po, (uint32_t)nx,
+                         (const uint64_t*)d_ptab, (const uint32_t*)((const uint64_t*)d_ptab + passes.size() * 2),
+                         (uint32_t)passes.size(), (uint32_t*)tile_x);
+      SHZ_HIP(ctx, hipGetLastError());
+      void* const tile_x_all = tile_x;
+      size_t pass_i = 0;
       for (const vpass& vp : passes) {
         const uint64_t pp = vp.v_hi - vp.v_lo;
         const uint32_t nqp = vp.qb - vp.qa;
         const uint32_t ntiles = (uint32_t)((pp + M_EXP_TILE - 1) / M_EXP_TILE);
         m_bits mbp = mb;
         if (use32) mbp.qb = nqp > 1 ? bits_for(nqp - 1) : 0;
-        hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint64_t*)po,
-                           (uint32_t)nx, vp.v_lo, vp.v_hi, ntiles, (uint32_t*)tile_x);
+        tile_x = (uint32_t*)tile_x_all + toff[pass_i++];
         uint32_t *rs = r_sid + (uint64_t)vp.qa * topn, *ra = r_al + (uint64_t)vp.qa * topn, *rd = r_dd + (uint64_t)vp.qa * topn;
         int32_t* rdl = (int32_t*)r_delta + (uint64_t)vp.qa * topn;
         if (use32) {
@@ -3031,7 +3091,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                                dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
                                (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
                                (uint32_t*)cdd + (uint64_t)nt * topn);
-            hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(256), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
+            hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
                                (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, hcap,
                                rs, rdl, ra, rd, r_n + vp.qa);
             SHZ_HIP(ctx, hipGetLastError());
