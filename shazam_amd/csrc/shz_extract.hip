@@ -627,6 +627,56 @@ __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __rest
   }
 }
 
+// The same from a per-FRAME exclusive scan of the peak counts (fp32 staging: peak_pick32 and peak_verify count the
+// peaks of every frame as they set mask bits, so the 25.8M-word popcount scan of a 1,000-clip batch -- three passes over
+// 206 MB and a 103 MB prefix array -- shrinks to a scan of 644,000 counts).  A workgroup owns 256 consecutive mask
+// words; all but one in a hundred hold no bit at all and end here.  Otherwise: prefix of the words inside the
+// workgroup, plus the peaks of the first word's frame that lie in front of the workgroup, plus that frame's offset.
+__global__ __launch_bounds__(256) void peak_expand_frames_kernel(const uint64_t* __restrict__ mask,
+                                                                 const uint32_t* __restrict__ frame_off, uint32_t n_words,
+                                                                 mask_geom mg, const uint32_t* __restrict__ frame_t,
+                                                                 uint16_t* __restrict__ peak_f, uint32_t* __restrict__ peak_t,
+                                                                 uint32_t cap) {
+  __shared__ uint32_t s_w[4], s_before;
+  const uint32_t w0 = blockIdx.x * 256u, w = w0 + threadIdx.x;
+  uint64_t m = w < n_words ? mask[w] : 0ull;
+  if (!__syncthreads_or(m != 0)) return;   // uniform
+  const uint32_t per_frame = mg.n_slabs * mg.nw;
+  const uint32_t g0 = w0 / per_frame, r0 = w0 - g0 * per_frame;   // r0 < 256 words of frame g0 precede the workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t before = threadIdx.x < r0 ? (uint32_t)__popcll(mask[(uint64_t)g0 * per_frame + threadIdx.x]) : 0u;
+  const uint32_t c = (uint32_t)__popcll(m);
+  uint32_t inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+  if (threadIdx.x == 0) s_before = 0;
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  if (lane == 0 && before) atomicAdd(&s_before, before);
+  __syncthreads();
+  if (!m) return;
+  uint32_t o = frame_off[g0] + s_before + inc - c;
+  for (int k = 0; k < wave; ++k) o += s_w[k];
+  const uint32_t g = w / per_frame;
+  const uint32_t rem = w - g * per_frame;
+  const uint32_t slab = rem / mg.nw, wv = rem % mg.nw;
+  const uint32_t t = frame_t[g];
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (o < cap) {
+      peak_f[o] = (uint16_t)(slab * mg.sw + wv * mg.lane_stride + b - 10);
+      peak_t[o] = t;
+    }
+    ++o;
+  }
+}
+
 // per-clip CSR offsets from a per-element exclusive scan: out[c] = scan[first[c]*mult] (or total at the end)
 __global__ void gather_offsets_kernel(const uint32_t* __restrict__ scan, const uint64_t* __restrict__ total,
                                       const uint32_t* __restrict__ first, uint64_t mult, uint64_t n_elems,
@@ -1256,7 +1306,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
     if (cap_peaks64 * (fan > 1 ? fan - 1 : 1) >= (1ull << 32))
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "sub-batch of %u frames may yield 2^32 hashes; lower the workspace limit", sb.frames);
     const uint32_t cap_peaks = (uint32_t)cap_peaks64;
-    void *d_mask, *d_woff, *d_und, *pf, *pt, *pc, *ft;
+    void *d_mask, *d_woff, *d_und, *pf, *pt, *pc, *ft, *d_fcnt = nullptr;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MASK, n_words * 8, &d_mask));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SCAN, n_words * 4, &d_woff));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, (uint64_t)cap_peaks * 2 + 64, &pf));
@@ -1268,6 +1318,8 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_UND, (uint64_t)UND_CAP * 8, &d_und));
       if (si) hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);   // (the block starts zeroed)
       SHZ_HIP(ctx, hipMemsetAsync(d_mask, 0, n_words * 8, ctx->stream));  // peak_pick32 writes non-zero words only
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)sb.frames * 4 + 64, &d_fcnt));
+      SHZ_HIP(ctx, hipMemsetAsync(d_fcnt, 0, (uint64_t)sb.frames * 4, ctx->stream));
       {
         shz_prof_scope ps(ctx, 1);
         p32_args pa;
@@ -1281,6 +1333,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         pa.und_list = (uint64_t*)d_und;
         pa.ctl = d_ctl;
         pa.und_cap = UND_CAP;
+        pa.frame_cnt = (uint32_t*)d_fcnt;
         switch (mg.nw * 10 + p32_occ()) {
           case 13: launch_pick32<1, 3>(ctx, pa, sd.n_segs); break;
           case 14: launch_pick32<1, 4>(ctx, pa, sd.n_segs); break;
@@ -1301,6 +1354,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         va.st = sa;
         va.A = (const float*)d_pw;
         va.mask = (uint64_t*)d_mask;
+        va.frame_cnt = (uint32_t*)d_fcnt;
         va.mg = mg;
         va.und_list = (const uint64_t*)d_und;
         va.ctl = d_ctl;
@@ -1330,18 +1384,27 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
     }
     {
       shz_prof_scope ps(ctx, 2);
-      SHZ_TRY(shz_scan_popc64(ctx, (const uint64_t*)d_mask, (uint32_t*)d_woff, n_words, (uint64_t*)&d_ctl->sub_peaks));
+      // offsets of the peaks: fp32 staging counted them per frame (d_woff = exclusive scan of the frames' counts),
+      // the fp64 kernels leave the mask only (d_woff = exclusive scan of the words' popcounts)
+      if (xp.f32) SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)d_fcnt, (uint32_t*)d_woff, sb.frames, (uint64_t*)&d_ctl->sub_peaks));
+      else SHZ_TRY(shz_scan_popc64(ctx, (const uint64_t*)d_mask, (uint32_t*)d_woff, n_words, (uint64_t*)&d_ctl->sub_peaks));
       hipLaunchKernelGGL(xctl_after_peaks_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl, cap_peaks, UND_CAP);
       if (n_words) {
         hipLaunchKernelGGL(frame_time_kernel, dim3((sb.frames + 255) / 256), dim3(256), 0, ctx->stream, sd.d_foff, nc,
                            sb.frames, (uint32_t*)ft);
-        hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
-                           (uint16_t*)pf, (uint32_t*)pt, cap_peaks);
+        if (xp.f32)
+          hipLaunchKernelGGL(peak_expand_frames_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                             (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
+                             (uint16_t*)pf, (uint32_t*)pt, cap_peaks);
+        else
+          hipLaunchKernelGGL(peak_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                             (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
+                             (uint16_t*)pf, (uint32_t*)pt, cap_peaks);
       }
       hipLaunchKernelGGL(gather_offsets_kernel, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                          (const uint32_t*)d_woff, (const uint64_t*)&d_ctl->sub_peaks, sd.d_foff,
-                         (uint64_t)mg.n_slabs * mg.nw, n_words, nc, (uint32_t*)pc, cap_peaks);
+                         xp.f32 ? (uint64_t)1 : (uint64_t)mg.n_slabs * mg.nw, xp.f32 ? (uint64_t)sb.frames : n_words, nc,
+                         (uint32_t*)pc, cap_peaks);
       SHZ_HIP(ctx, hipGetLastError());
     }
     if (!want_hashes) {
