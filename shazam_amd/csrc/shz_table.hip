@@ -2147,6 +2147,7 @@ static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 #define VT_MAXTOPN 8
 #define VT_MAX_DBITS 12
 #define VT_EMPTY 0xFFFFFFFFu
+#define VT_ONE_WG_MAX 32768     // votes of a single query that one workgroup folds without any radix pass
 
 struct vt_plan {
   uint32_t nq;                 // queries of the pass
@@ -2623,6 +2624,15 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
   }
 }
 
+// one query whose votes one workgroup can fold as they come out of the expand (no radix pass at all): the whole pass is
+// the one range handed to vt_fold_kernel
+__global__ void vt_one_range_kernel(uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy, uint32_t* __restrict__ heavy_q,
+                                    uint32_t n_votes) {
+  *n_heavy = 1u;
+  heavy[0] = make_uint2(0u, n_votes);
+  heavy_q[0] = 0u;
+}
+
 // one workgroup per query of the pass: top-n of its tiles' candidates
 #define VR_THREADS 1024
 #define VR_CACHE 12            // candidates a thread keeps in registers: 12,288 per query before it re-reads them
@@ -3014,6 +3024,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         if (force32 != 1 && P / std::max<size_t>(passes.size(), 1) < (1ull << 22)) use32 = false;   // small passes: launch-bound
       }
       if (!use32) { passes.clear(); passes.push_back(vpass{0, nq, 0, P}); }
+      // ONE query with few votes (a 5-10 s query against thousands of songs): expand, then one workgroup folds the
+      // unordered votes (vt_fold_kernel over the single range [0, P)) -- 5 launches instead of the 9 of sort + fold,
+      // and the launches are what such a match costs
+      const bool one_wg = !use32 && nq == 1 && P <= VT_ONE_WG_MAX && qbits32 >= 0 && tiles_env != 0 && topn <= VT_MAXTOPN &&
+                          mb.dbits <= VT_MAX_DBITS;
       uint64_t pmax = 0;
       for (const vpass& vp : passes) pmax = std::max(pmax, vp.v_hi - vp.v_lo);
       void *v0, *v1;   // E lives in one of SORT_A/B; the vote buffers use SORT_C/D
@@ -3029,13 +3044,18 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         toff[i + 1] = toff[i] + (uint32_t)((passes[i].v_hi - passes[i].v_lo + M_EXP_TILE - 1) / M_EXP_TILE) + 1;
       }
       memcpy(ptab.data() + passes.size() * 2, toff.data(), toff.size() * 4);
-      void* d_ptab;
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT4, ptab.size() * 8, &d_ptab));
-      SHZ_HIP(ctx, shz_memcpy(ctx, d_ptab, ptab.data(), ptab.size() * 8, hipMemcpyHostToDevice));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)toff.back() * 4, &tile_x));   // (M5 belongs to the fold)
-      hipLaunchKernelGGL(m_tile_start_all_kernel, dim3(nblk(toff.back())), dim3(256), 0, ctx->stream, (const uint64_t*)po, (uint32_t)nx,
-                         (const uint64_t*)d_ptab, (const uint32_t*)((const uint64_t*)d_ptab + passes.size() * 2),
-                         (uint32_t)passes.size(), (uint32_t*)tile_x);
+      if (passes.size() == 1) {   // no table to send up
+        hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk(toff.back())), dim3(256), 0, ctx->stream, (const uint64_t*)po, (uint32_t)nx,
+                           passes[0].v_lo, passes[0].v_hi, toff.back() - 1, (uint32_t*)tile_x);
+      } else {
+        void* d_ptab;
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT4, ptab.size() * 8, &d_ptab));
+        SHZ_HIP(ctx, shz_memcpy(ctx, d_ptab, ptab.data(), ptab.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(m_tile_start_all_kernel, dim3(nblk(toff.back())), dim3(256), 0, ctx->stream, (const uint64_t*)po, (uint32_t)nx,
+                           (const uint64_t*)d_ptab, (const uint32_t*)((const uint64_t*)d_ptab + passes.size() * 2),
+                           (uint32_t)passes.size(), (uint32_t*)tile_x);
+      }
       SHZ_HIP(ctx, hipGetLastError());
       void* const tile_x_all = tile_x;
       size_t pass_i = 0;
@@ -3048,7 +3068,34 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         tile_x = (uint32_t*)tile_x_all + toff[pass_i++];
         uint32_t *rs = r_sid + (uint64_t)vp.qa * topn, *ra = r_al + (uint64_t)vp.qa * topn, *rd = r_dd + (uint64_t)vp.qa * topn;
         int32_t* rdl = (int32_t*)r_delta + (uint64_t)vp.qa * topn;
-        if (use32) {
+        if (one_wg) {
+          uint32_t* k32 = (uint32_t*)v0;
+          hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                             (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
+                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp, (int64_t)0, k32);
+          vt_plan pl;
+          pl.nq = 1;
+          pl.dbits = mbp.dbits;
+          pl.sb = mbp.sb;
+          pl.g_lo = mbp.sb + mbp.dbits + 1;   // no bit is ordered: a sweep may split by any song-id bit
+          pl.tile = VW_CHUNK;
+          for (uint32_t i = 0; i <= VT_MAXQ; ++i) { pl.qv[i] = i ? (uint32_t)pp : 0u; pl.tb[i] = 0; }   // no tiles, one range
+          void *ts, *cp, *cd, *cdd;
+          SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, 64, &ts));
+          SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT1, (uint64_t)topn * 8, &cp));
+          SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT2, (uint64_t)topn * 4, &cd));
+          SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT3, (uint64_t)topn * 4, &cdd));
+          uint32_t* n_heavy = (uint32_t*)ts;
+          uint2* heavy = (uint2*)(n_heavy + 2);
+          uint32_t* heavy_q = n_heavy + 4;
+          hipLaunchKernelGGL(vt_one_range_kernel, dim3(1), dim3(1), 0, ctx->stream, n_heavy, heavy, heavy_q, (uint32_t)pp);
+          hipLaunchKernelGGL(vt_fold_kernel, dim3(1), dim3(VT_THREADS), 0, ctx->stream, (const uint32_t*)k32, (const uint2*)heavy,
+                             (const uint32_t*)n_heavy, 1u, pl, topn, (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd);
+          hipLaunchKernelGGL(vt_rank_kernel, dim3(1), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
+                             (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, 1u,
+                             rs, rdl, ra, rd, r_n + vp.qa);
+          SHZ_HIP(ctx, hipGetLastError());
+        } else if (use32) {
           uint32_t* k32 = (uint32_t*)v0;   // two 4-byte buffers in SORT_C, the widened result in SORT_D
           hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                              (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
