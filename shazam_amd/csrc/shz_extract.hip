@@ -632,20 +632,32 @@ __global__ __launch_bounds__(256) void peak_expand_kernel(const uint64_t* __rest
 // 206 MB and a 103 MB prefix array -- shrinks to a scan of 644,000 counts).  A workgroup owns 256 consecutive mask
 // words; all but one in a hundred hold no bit at all and end here.  Otherwise: prefix of the words inside the
 // workgroup, plus the peaks of the first word's frame that lie in front of the workgroup, plus that frame's offset.
+#define PXF_PER 8   // mask words per thread: a workgroup reads 16 KB before it decides whether there is anything to do
 __global__ __launch_bounds__(256) void peak_expand_frames_kernel(const uint64_t* __restrict__ mask,
                                                                  const uint32_t* __restrict__ frame_off, uint32_t n_words,
                                                                  mask_geom mg, const uint32_t* __restrict__ frame_t,
                                                                  uint16_t* __restrict__ peak_f, uint32_t* __restrict__ peak_t,
                                                                  uint32_t cap) {
   __shared__ uint32_t s_w[4], s_before;
-  const uint32_t w0 = blockIdx.x * 256u, w = w0 + threadIdx.x;
-  uint64_t m = w < n_words ? mask[w] : 0ull;
-  if (!__syncthreads_or(m != 0)) return;   // uniform
+  const uint32_t w0 = blockIdx.x * (256u * PXF_PER), w1 = w0 + threadIdx.x * PXF_PER;   // the thread's first word
+  uint64_t m[PXF_PER];
+  if (w1 + PXF_PER <= n_words) {
+    const ulonglong2* p2 = (const ulonglong2*)(mask + w1);   // the mask buffer and w1 * 8 are 16-byte aligned
+#pragma unroll
+    for (int i = 0; i < PXF_PER / 2; ++i) { const ulonglong2 x = p2[i]; m[2 * i] = x.x; m[2 * i + 1] = x.y; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PXF_PER; ++i) m[i] = w1 + i < n_words ? mask[w1 + i] : 0ull;
+  }
+  uint64_t any = 0;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < PXF_PER; ++i) { any |= m[i]; c += (uint32_t)__popcll(m[i]); }
+  if (!__syncthreads_or(any != 0)) return;   // uniform
   const uint32_t per_frame = mg.n_slabs * mg.nw;
   const uint32_t g0 = w0 / per_frame, r0 = w0 - g0 * per_frame;   // r0 < 256 words of frame g0 precede the workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t before = threadIdx.x < r0 ? (uint32_t)__popcll(mask[(uint64_t)g0 * per_frame + threadIdx.x]) : 0u;
-  const uint32_t c = (uint32_t)__popcll(m);
   uint32_t inc = c;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -659,21 +671,27 @@ __global__ __launch_bounds__(256) void peak_expand_frames_kernel(const uint64_t*
   __syncthreads();
   if (lane == 0 && before) atomicAdd(&s_before, before);
   __syncthreads();
-  if (!m) return;
+  if (!any) return;
   uint32_t o = frame_off[g0] + s_before + inc - c;
   for (int k = 0; k < wave; ++k) o += s_w[k];
-  const uint32_t g = w / per_frame;
-  const uint32_t rem = w - g * per_frame;
-  const uint32_t slab = rem / mg.nw, wv = rem % mg.nw;
-  const uint32_t t = frame_t[g];
-  while (m) {
-    const int b = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (o < cap) {
-      peak_f[o] = (uint16_t)(slab * mg.sw + wv * mg.lane_stride + b - 10);
-      peak_t[o] = t;
+#pragma unroll
+  for (int i = 0; i < PXF_PER; ++i) {
+    uint64_t mm = m[i];
+    if (!mm) continue;
+    const uint32_t w = w1 + i;
+    const uint32_t g = w / per_frame;
+    const uint32_t rem = w - g * per_frame;
+    const uint32_t slab = rem / mg.nw, wv = rem % mg.nw;
+    const uint32_t t = frame_t[g];
+    while (mm) {
+      const int bb = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      if (o < cap) {
+        peak_f[o] = (uint16_t)(slab * mg.sw + wv * mg.lane_stride + bb - 10);
+        peak_t[o] = t;
+      }
+      ++o;
     }
-    ++o;
   }
 }
 
@@ -1393,7 +1411,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         hipLaunchKernelGGL(frame_time_kernel, dim3((sb.frames + 255) / 256), dim3(256), 0, ctx->stream, sd.d_foff, nc,
                            sb.frames, (uint32_t*)ft);
         if (xp.f32)
-          hipLaunchKernelGGL(peak_expand_frames_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+          hipLaunchKernelGGL(peak_expand_frames_kernel, dim3((unsigned)((n_words + 256 * PXF_PER - 1) / (256 * PXF_PER))), dim3(256), 0, ctx->stream,
                              (const uint64_t*)d_mask, (const uint32_t*)d_woff, (uint32_t)n_words, mg, (const uint32_t*)ft,
                              (uint16_t*)pf, (uint32_t*)pt, cap_peaks);
         else
