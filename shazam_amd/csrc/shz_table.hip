@@ -2289,17 +2289,6 @@ __device__ __forceinline__ uint32_t vt_wave_max(uint32_t v) {
   return max(max(r0, r1), max(r2, r3));
 }
 
-#ifdef VT_PROFILE
-__device__ unsigned long long vt_prof[16];
-#define VT_STAMP(i) do { if (j == 0) { const unsigned long long now_ = wall_clock64(); t_acc[i] += now_ - t_last; t_last = now_; } } while (0)
-extern "C" int32_t shz_debug_vt_prof(unsigned long long* out) {
-  unsigned long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vt_prof), sizeof(z)) != hipSuccess) return SHZ_E_HIP;
-  return hipMemcpyToSymbol(HIP_SYMBOL(vt_prof), z, sizeof(z)) == hipSuccess ? SHZ_OK : SHZ_E_HIP;
-}
-#else
-#define VT_STAMP(i)
-#endif
 
 // Persistent workgroups, tile g = blockIdx.x, + gridDim.x, ...  Per tile (and per sweep of an over-full tile):
 //   A  every vote: vt_votes (both tables at once)
@@ -2325,9 +2314,6 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
   uint32_t* const cnt = key1 + VT_SLOTS;
   const uint32_t j = threadIdx.x, lane = j & 63, nt = min(*n_ranges, cap);
   if (blockIdx.x >= nt) return;   // the usual case: nothing was handed over
-#ifdef VT_PROFILE
-  unsigned long long t_last = wall_clock64(), t_acc[8] = {0};
-#endif
   const uint32_t dmask = (1u << pl.dbits) - 1u, smask = (pl.sb >= 32 ? ~0u : (1u << pl.sb) - 1u);
   const int slb = pl.g_lo - 1 - pl.dbits;           // song-id bits below the ordered ones: what sweeps may split by
   auto clear1 = [&]() {
@@ -2350,7 +2336,6 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
     const bool checked = b - a > VT_LIMIT2;         // fewer votes than either table may hold: no sweep can overflow
     int cl = 0, nsl = 0;                             // candidate list in use, log2 of the number of sweeps
     bool prefetched = false;
-    VT_STAMP(0);
     for (bool done = (a >= b); !done;) {             // until a sweep count is found under which every sweep fits
       bool over = false;
       cl = 0;
@@ -2380,7 +2365,6 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
         }
         static_assert(VT_ROWS == 3, "the row select above names pre[0..2]");
         __syncthreads();
-        VT_STAMP(1);
         const uint32_t n2 = s_n2;
         if (!prefetched) {               // the next tile's first rows: in flight during C and D
           prefetched = true;
@@ -2430,14 +2414,12 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
           }
         }
         __syncthreads();
-        VT_STAMP(2);
         // ---- D (also what an overflowing sweep leaves behind)
         clear1();
         for (uint32_t e = j; e < n2; e += VT_THREADS) { const uint32_t s = lst[e]; key2[s] = VT_EMPTY; best[s] = 0; ded[s] = 0; }
         if (j == 0) { s_n1 = 0; s_n2 = 0; }
         if (!over) cl ^= 1;
         __syncthreads();
-        VT_STAMP(3);
       }
       if (!over) { done = true; break; }
       // at nsl == slb a sweep is one song of the last group (<= 2^VT_MAX_DBITS deltas) + less than VT_TILE other votes,
@@ -2458,17 +2440,9 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
       c_dedup[o] = any ? s_cdedup[cl][j] : 0u;
     }
     __syncthreads();   // the candidate lists are rewritten by the next tile
-    VT_STAMP(4);
-#ifdef VT_PROFILE
-    if (j == 0) t_acc[7] += 1;
-#endif
     a = na;
     b = nb;
   }
-#ifdef VT_PROFILE
-  if (j == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&vt_prof[i], t_acc[i]);
-#endif
 }
 
 // ---- the usual path: one WAVE per tile of ~VW_CHUNK votes, streaming through it with wave-private tables.
