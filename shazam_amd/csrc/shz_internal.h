@@ -153,6 +153,16 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
 
 // stable LSD radix sort of 4-byte keys on bits [bit_lo, bit_hi) (k0 <-> k1 ping-pong); the result is written to out64 as
 // 8-byte keys, key + add
+// segments of a segmented 4-byte sort (shz_sort_u32_seg): segment i holds the keys [qv[i], qv[i + 1]) and is cut into
+// the blocks [bq[i], bq[i + 1]) of <= 4,096 keys; no block crosses a segment border
+#define SHZ_SEG_MAX 32
+struct shz_seg_plan {
+  uint32_t nq;
+  uint32_t qv[SHZ_SEG_MAX + 1];
+  uint32_t bq[SHZ_SEG_MAX + 1];
+};
+int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp,
+                         int* sel);
 int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
                            uint64_t add, int* sel);
 

@@ -617,6 +617,193 @@ int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* o
   return SHZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// SEGMENTED form of the 4-byte sort: the keys of segment i stay inside [qv[i], qv[i+1]) and are ordered among
+// themselves.  The votes of a pass come out of the expand query by query, so the query index needs no bits of the
+// key: a pass holds as many queries as the vote budget allows, not the two that a 32-bit key has a spare bit for, and
+// every per-pass launch (scans of the digit tables, tile bounds, rank) is paid once per ~30 queries instead of once
+// per two.  Blocks of <= 4,096 keys never cross a segment border; the digit table is laid out segment-major
+// ([segment][digit][block of the segment]), so ONE linear exclusive scan yields every block's destinations: keys of
+// earlier segments, then smaller digits of the own segment, then the same digit in earlier blocks of the segment.
+__device__ __forceinline__ void seg_of_block(const shz_seg_plan& sp, uint32_t b, uint32_t& seg, uint32_t& lo, uint32_t& len,
+                                             uint32_t& hbase, uint32_t& nbs) {
+  uint32_t i = 0;
+  while (i + 1 < sp.nq && sp.bq[i + 1] <= b) ++i;   // bq[i] <= b < bq[i + 1]; empty segments have no blocks
+  seg = i;
+  const uint32_t bl = b - sp.bq[i];
+  lo = sp.qv[i] + bl * SORT_TILE;
+  len = min((uint32_t)SORT_TILE, sp.qv[i + 1] - lo);
+  nbs = sp.bq[i + 1] - sp.bq[i];
+  hbase = bl;                                       // + (bq[i] << BITS) + digit * nbs
+}
+
+template <int BITS>
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uint32_t* __restrict__ keys, shz_seg_plan sp, int shift,
+                                                                        uint32_t dmask, uint32_t* __restrict__ hist) {
+  constexpr uint32_t DIG = 1u << BITS;
+  __shared__ uint32_t h[DIG];
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) h[d] = 0;
+  __syncthreads();
+  uint32_t seg, lo, len, hb, nbs;
+  seg_of_block(sp, blockIdx.x, seg, lo, len, hb, nbs);
+  // a segment starts wherever its query's votes start: up to three keys in front of the first 16-byte boundary and
+  // behind the last one are counted singly, the rest four per load
+  const uint32_t head = min((4u - (lo & 3u)) & 3u, len), nv = (len - head) >> 2, tail0 = head + 4u * nv;
+  {
+    const uint4* k4 = (const uint4*)(keys + lo + head);
+    uint4 x[SORT_ROUNDS / 4];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 4; ++r) {
+      const uint32_t i = (uint32_t)r * SORT_THREADS + threadIdx.x;
+      x[r] = i < nv ? k4[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS / 4; ++r) {
+      if ((uint32_t)r * SORT_THREADS + threadIdx.x < nv) {
+        atomicAdd(&h[(x[r].x >> shift) & dmask], 1u);
+        atomicAdd(&h[(x[r].y >> shift) & dmask], 1u);
+        atomicAdd(&h[(x[r].z >> shift) & dmask], 1u);
+        atomicAdd(&h[(x[r].w >> shift) & dmask], 1u);
+      }
+    }
+    if (threadIdx.x < head) atomicAdd(&h[(keys[lo + threadIdx.x] >> shift) & dmask], 1u);
+    if (tail0 + threadIdx.x < len) atomicAdd(&h[(keys[lo + tail0 + threadIdx.x] >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  const uint64_t base = ((uint64_t)sp.bq[seg] << BITS) + hb;
+#pragma unroll
+  for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) hist[base + (uint64_t)d * nbs] = h[d];
+}
+
+template <int BITS>
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ okeys,
+                                                                           uint64_t n, shz_seg_plan sp, int shift, uint32_t dmask,
+                                                                           const uint32_t* __restrict__ offs, uint64_t n_hist) {
+  constexpr uint32_t DIG = 1u << BITS;
+  constexpr int DPT = DIG / SORT_THREADS;
+  __shared__ uint32_t skey[SORT_TILE];
+  __shared__ uint32_t gbase[DIG];
+  __shared__ uint16_t lstart[DIG];
+  __shared__ uint16_t wrun[4][DIG];
+  __shared__ uint32_t scan_tmp[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t seg, lo, tile_n, hb, nbs;
+  seg_of_block(sp, blockIdx.x, seg, lo, tile_n, hb, nbs);
+  constexpr int ROWS = SORT_TILE / SORT_THREADS;
+  uint32_t k[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    k[r] = li < tile_n ? keys[lo + li] : 0;
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) wrun[w][threadIdx.x * DPT + i] = 0;
+  {
+    uint32_t g0[DPT], c[DPT], sum = 0;
+    const uint64_t base = ((uint64_t)sp.bq[seg] << BITS) + hb;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const uint64_t f = base + (uint64_t)(threadIdx.x * DPT + i) * nbs;
+      g0[i] = offs[f];
+      const uint32_t g1 = (f + 1 < n_hist) ? offs[f + 1] : (uint32_t)n;   // the next entry of the scan: own count behind g0
+      c[i] = g1 - g0[i];
+      sum += c[i];
+    }
+    uint32_t tot;
+    uint32_t ls = block_excl_scan<uint32_t>(sum, &tot, scan_tmp);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      gbase[threadIdx.x * DPT + i] = g0[i];
+      lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
+      ls += c[i];
+    }
+  }
+  __syncthreads();
+  uint32_t rank[ROWS];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    const bool valid = li < tile_n;
+    const uint32_t d = (k[r] >> shift) & dmask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    const uint32_t run = wrun[wave][d];
+    rank[r] = run + rk;
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) {
+    const uint32_t d = threadIdx.x * DPT + i;
+    const uint32_t c0 = wrun[0][d], c1 = wrun[1][d], c2 = wrun[2][d];
+    const uint32_t ls = lstart[d];
+    wrun[0][d] = (uint16_t)ls;
+    wrun[1][d] = (uint16_t)(ls + c0);
+    wrun[2][d] = (uint16_t)(ls + c0 + c1);
+    wrun[3][d] = (uint16_t)(ls + c0 + c1 + c2);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
+    if (li < tile_n) {
+      const uint32_t d = (k[r] >> shift) & dmask;
+      skey[wrun[wave][d] + rank[r]] = k[r];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
+    const uint32_t kk = skey[i];
+    const uint32_t d = (kk >> shift) & dmask;
+    okeys[gbase[d] + (i - lstart[d])] = kk;
+  }
+}
+
+int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp,
+                         int* sel) {
+  if (sel) *sel = 0;
+  if (n == 0 || bit_hi <= bit_lo) return SHZ_OK;
+  if (n >= (1ull << 32) || bit_hi > 32) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: n %llu, bits [%d, %d)", (unsigned long long)n, bit_lo, bit_hi);
+  const uint32_t nblocks = sp.bq[sp.nq];
+  const int bits = bit_hi - bit_lo;
+  const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
+  const bool wide = np9 < np8;
+  void* hist;
+  const uint64_t n_hist = (uint64_t)nblocks << (wide ? 9 : 8);
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, n_hist * 4, &hist));
+  uint32_t *kin = k0, *kout = k1;
+  int left = wide ? np9 : np8;
+  for (int shift = bit_lo; shift < bit_hi; --left) {
+    const int w = wide ? (bit_hi - shift + left - 1) / left : 8;
+    const int wb = w == 9 ? 9 : 8;
+    const uint32_t dmask = (1u << std::min(wb, bit_hi - shift)) - 1u;
+    const uint64_t nh = (uint64_t)nblocks << wb;
+    if (wb == 9) {
+      hipLaunchKernelGGL(sort_hist32_seg_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, sp, shift, dmask, (uint32_t*)hist);
+      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, nh, nullptr));
+      hipLaunchKernelGGL(sort_scatter32_seg_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+    } else {
+      hipLaunchKernelGGL(sort_hist32_seg_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, sp, shift, dmask, (uint32_t*)hist);
+      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, nh, nullptr));
+      hipLaunchKernelGGL(sort_scatter32_seg_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+    }
+    SHZ_HIP(ctx, hipGetLastError());
+    shift += wb;
+    std::swap(kin, kout);
+  }
+  if (sel) *sel = kin == k1 ? 1 : 0;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
                                    uint64_t add, uint64_t* out64) {
   if (!ctx) return SHZ_E_INVALID;

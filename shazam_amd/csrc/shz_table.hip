@@ -1630,8 +1630,9 @@ __global__ void m_tile_start_all_kernel(const uint64_t* __restrict__ po, uint32_
   tile_x[e] = l;
 }
 
+#define M_NO_QUERY_BITS INT64_MIN   // q_base of a pass whose votes carry no query index (segmented sort: position says it)
 __device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t off, uint32_t first, m_bits mb, int64_t q_base) {
-  const uint64_t q = (uint64_t)((int64_t)(e >> QIDX_SHIFT) + q_base);
+  const uint64_t q = q_base == M_NO_QUERY_BITS ? 0ull : (uint64_t)((int64_t)(e >> QIDX_SHIFT) + q_base);
   const uint32_t qo = (uint32_t)e & ((1u << QOFF_BITS) - 1);
   const uint64_t dprime = (uint64_t)off + mb.bias - qo;  // delta + bias >= 0
   return ((((q << mb.sb) | sid) << mb.dbits | dprime) << 1) | first;
@@ -2143,10 +2144,13 @@ static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 #define VT_SLOTS 8192          // per LDS table (4 arrays of 4 bytes x VT_SLOTS = 128 KB)
 #define VT_TILE 2048           // votes per tile before the cut is moved to the next group border
 #define VT_LIMIT 6144          // distinct keys a table may hold: VT_TILE + 2^12 deltas of one song always fit one sweep
-#define VT_MAXQ 16             // queries per vote pass
+#define VT_MAXQ SHZ_SEG_MAX     // queries per vote pass (their votes stay apart as segments of the sort: shz_sort_u32_seg)
 #define VT_MAXTOPN 8
 #define VT_MAX_DBITS 12
 #define VT_EMPTY 0xFFFFFFFFu
+#ifndef VT_ORDERED_BITS
+#define VT_ORDERED_BITS 16     // upper bits of a vote the radix passes order (two passes of 8)
+#endif
 #define VT_ONE_WG_MAX 32768     // votes of a single query that one workgroup folds without any radix pass
 
 struct vt_plan {
@@ -2985,7 +2989,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
       const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS;
       if (use32) {
-        const uint32_t q_per_pass = tiles ? std::min<uint32_t>(1u << std::min(qbits32, 30), VT_MAXQ) : (1u << std::min(qbits32, 30));
+        const uint32_t q_per_pass = tiles ? (uint32_t)VT_MAXQ : (1u << std::min(qbits32, 30));   // tiles: no query bits in the vote
         uint64_t v = 0;
         for (uint32_t qa = 0; qa < nq;) {
           uint32_t qb = qa;
@@ -3038,7 +3042,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         const uint32_t nqp = vp.qb - vp.qa;
         const uint32_t ntiles = (uint32_t)((pp + M_EXP_TILE - 1) / M_EXP_TILE);
         m_bits mbp = mb;
-        if (use32) mbp.qb = nqp > 1 ? bits_for(nqp - 1) : 0;
+        if (use32) mbp.qb = (nqp > 1 && !tiles) ? bits_for(nqp - 1) : 0;
         tile_x = (uint32_t*)tile_x_all + toff[pass_i++];
         uint32_t *rs = r_sid + (uint64_t)vp.qa * topn, *ra = r_al + (uint64_t)vp.qa * topn, *rd = r_dd + (uint64_t)vp.qa * topn;
         int32_t* rdl = (int32_t*)r_delta + (uint64_t)vp.qa * topn;
@@ -3073,26 +3077,34 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
           uint32_t* k32 = (uint32_t*)v0;   // two 4-byte buffers in SORT_C, the widened result in SORT_D
           hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                              (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
-                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp, -(int64_t)vp.qa, k32);
+                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp,
+                             tiles ? M_NO_QUERY_BITS : -(int64_t)vp.qa, k32);
           SHZ_HIP(ctx, hipGetLastError());
           const int B = mbp.qb + mbp.sb + mbp.dbits + 1;
           if (tiles) {
             vt_plan pl;
-            pl.nq = nqp;
+            shz_seg_plan sp;
+            const int Bt = mbp.sb + mbp.dbits + 1;   // the votes of a tile pass carry no query bits
+            pl.nq = sp.nq = nqp;
             pl.dbits = mbp.dbits;
             pl.sb = mbp.sb;
-            pl.g_lo = std::max(1 + mbp.dbits, B - 16);
+            pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
             pl.tile = VW_CHUNK;
-            pl.qv[0] = pl.tb[0] = 0;
+            pl.qv[0] = pl.tb[0] = sp.qv[0] = sp.bq[0] = 0;
             for (uint32_t i = 0; i < nqp; ++i) {
               const uint64_t c = nq > 1 ? h_votes[vp.qa + i] : pp;
-              pl.qv[i + 1] = pl.qv[i] + (uint32_t)c;
+              pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[i] + (uint32_t)c;
               pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + VW_CHUNK - 1) / VW_CHUNK);
+              sp.bq[i + 1] = sp.bq[i] + (uint32_t)((c + 4095) / 4096);
             }
-            for (uint32_t i = nqp; i < VT_MAXQ; ++i) { pl.qv[i + 1] = pl.qv[nqp]; pl.tb[i + 1] = pl.tb[nqp]; }
+            for (uint32_t i = nqp; i < VT_MAXQ; ++i) {
+              pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[nqp];
+              pl.tb[i + 1] = pl.tb[nqp];
+              sp.bq[i + 1] = sp.bq[nqp];
+            }
             const uint32_t nt = pl.tb[nqp], hcap = nt * VW_HEAVY_PER_TILE;
             int sel = 0;
-            SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, nullptr, pp, pl.g_lo, B, 0, &sel));
+            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax, pp, pl.g_lo, Bt, sp, &sel));
             const uint32_t* ks = sel ? k32 + pmax : k32;
             // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
             void *ts, *cp, *cd, *cdd;
