@@ -86,6 +86,7 @@ struct shz_ctx {
   double* d_window = nullptr;   // hann(4096)
   double2* d_twiddle = nullptr; // W4096^k, k in [0,1024]
   int16_t* d_sine_lut = nullptr;
+  double m_votes_per_hash = 0.0;   // votes per query hash of the last match sub-batch: sizes the next one before it is tried
   double win_sumsq = 0.0;
   // timers / profiling
   hipEvent_t tev[16][2];

@@ -2762,7 +2762,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   if (!vs_out && (topn < 1 || topn > 64)) SHZ_FAIL(ctx, SHZ_E_INVALID, "topn must be in [1,64]");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   ctx->st_rows = ctx->st_pairs = ctx->st_keys = 0;
-  const uint64_t P_BUDGET = 1ull << 28;
+  const uint64_t P_BUDGET = 1ull << 28;     // votes of one vote pass (its buffers: 2 x 4 or 8 bytes per vote)
+  const uint64_t SUB_BUDGET = 1ull << 30;   // votes of one sub-batch of queries (one head: compose, sort, probe, one round trip)
   // segment descriptors for the kernels (an empty table probes one empty segment)
   std::vector<shz_seg_dev> hsegs;
   for (const shz_seg& g : all_segs(t)) hsegs.push_back(shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets});
@@ -2819,6 +2820,17 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   uint32_t step = std::min<uint32_t>(n_queries, MAX_Q_SUB);
   while (q0 < n_queries) {
     uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
+    // the vote budget: sized from what a hash yielded in the last sub-batch, so that the head (compose, sort, probe: a
+    // round trip) is not run on 200 queries, then 100, then 50 to find that 25 fit
+    if (ctx->m_votes_per_hash > 0.0 && nq > 1) {
+      const double hashes = (double)SUB_BUDGET / (1.05 * ctx->m_votes_per_hash);
+      uint32_t lo = 1, hi = nq;   // largest count whose hashes stay under the estimate
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if ((double)(query_off[q0 + mid] - query_off[q0]) <= hashes) lo = mid; else hi = mid - 1;
+      }
+      nq = lo;
+    }
     // shrink so the element count stays sortable
     while (nq > 1 && query_off[q0 + nq] - query_off[q0] >= (1ull << 31)) nq /= 2;
     const uint64_t m = query_off[q0 + nq] - query_off[q0];
@@ -2950,7 +2962,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint32_t ng = (uint32_t)h.ng;
     const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
     const uint64_t P = h.P, rows_total = h.rows;
-    if (P > P_BUDGET && nq > 1) {  // too many pairs for one pass: retry with fewer queries
+    if (mu) ctx->m_votes_per_hash = (double)P / (double)mu;
+    if (P > SUB_BUDGET && nq > 1) {  // too many pairs for one sub-batch: retry with fewer queries
       step = std::max<uint32_t>(1, nq / 2);
       continue;
     }
