@@ -156,7 +156,7 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
 // 8-byte keys, key + add
 // segments of a segmented 4-byte sort (shz_sort_u32_seg): segment i holds the keys [qv[i], qv[i + 1]) and is cut into
 // the blocks [bq[i], bq[i + 1]) of <= 4,096 keys; no block crosses a segment border
-#define SHZ_SEG_MAX 32
+#define SHZ_SEG_MAX 128
 struct shz_seg_plan {
   uint32_t nq;
   uint32_t qv[SHZ_SEG_MAX + 1];

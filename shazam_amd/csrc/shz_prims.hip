@@ -627,8 +627,11 @@ int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* o
 // earlier segments, then smaller digits of the own segment, then the same digit in earlier blocks of the segment.
 __device__ __forceinline__ void seg_of_block(const shz_seg_plan& sp, uint32_t b, uint32_t& seg, uint32_t& lo, uint32_t& len,
                                              uint32_t& hbase, uint32_t& nbs) {
-  uint32_t i = 0;
-  while (i + 1 < sp.nq && sp.bq[i + 1] <= b) ++i;   // bq[i] <= b < bq[i + 1]; empty segments have no blocks
+  uint32_t i = 0, hi = sp.nq;                        // last segment with bq[i] <= b (empty segments have no blocks)
+  while (hi - i > 1) {
+    const uint32_t mid = (i + hi) >> 1;
+    if (sp.bq[mid] <= b) i = mid; else hi = mid;
+  }
   seg = i;
   const uint32_t bl = b - sp.bq[i];
   lo = sp.qv[i] + bl * SORT_TILE;

@@ -2163,8 +2163,11 @@ struct vt_plan {
 };
 
 __device__ __forceinline__ uint32_t vt_query_of_tile(const vt_plan& pl, uint32_t g) {
-  uint32_t i = 0;
-  while (i + 1 < pl.nq && pl.tb[i + 1] <= g) ++i;   // tb[i] <= g < tb[i + 1]; queries without votes have no tiles
+  uint32_t i = 0, hi = pl.nq;                        // last query with tb[i] <= g (queries without votes have no tiles)
+  while (hi - i > 1) {
+    const uint32_t mid = (i + hi) >> 1;
+    if (pl.tb[mid] <= g) i = mid; else hi = mid;
+  }
   return i;
 }
 
