@@ -2460,22 +2460,23 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
 // pairs: copies of one recording, stationary tones -- is handed to vt_fold_kernel as the range [batch start, next
 // group border): at most VW_FLUSH + 64 votes in front of its last group, so that kernel's bound holds for it too.
 #define VW_B1 9
-#define VW_B2 8
 #define VW_S1 (1 << VW_B1)     // (song | delta) entries of a batch
-#define VW_S2 (1 << VW_B2)     // songs of a batch
 #define VW_LIMIT1 384
-#define VW_LIMIT2 176
 #define VW_FLUSH 64
 #define VW_CHUNK 2048
-#define VW_HEAVY_PER_TILE 16   // every range has more than VW_LIMIT2 votes: at most 10 inside the nominal tile + the one around its last group
-static_assert(VW_LIMIT1 + 64 < VW_S1 && VW_LIMIT2 + 64 < VW_S2, "a probe must find a free slot");
+// songs of a batch: 2^B2 slots, B2 = 7 (2 KB, 26 waves per CU) where a batch is expected to hold few songs, else 8
+#define VW_HEAVY_PER_TILE 40   // a range handed over has more than 2^7 - 68 votes: at most 34 inside the nominal tile + the one around its last group
+static_assert(VW_LIMIT1 + 64 < VW_S1, "a probe must find a free slot");
 static_assert(VW_FLUSH + 64 <= VT_TILE, "a range handed to vt_fold_kernel has less than VT_TILE votes before its last group");
 
+template <int VW_B2>
 __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restrict__ k, const uint32_t* __restrict__ tile_start,
                                                        vt_plan pl, uint32_t topn, uint64_t* __restrict__ c_pack,
                                                        uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
                                                        uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
                                                        uint32_t* __restrict__ heavy_q, uint32_t heavy_cap) {
+  constexpr int VW_S2 = 1 << VW_B2;
+  constexpr uint32_t VW_LIMIT2 = VW_S2 - 68;        // + one row of new songs stays below VW_S2
   __shared__ uint4 t1[VW_S1 / 2];                    // key1[VW_S1] | cnt[VW_S1]
   __shared__ uint4 t2[VW_S2];                        // key2[VW_S2] | ded[VW_S2] | best[VW_S2] (8 bytes each)
   uint32_t* const key1 = (uint32_t*)t1;
@@ -2494,9 +2495,10 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
 #pragma unroll
     for (int i = 0; i < VW_S1 / 4 / 64; ++i) t1[VW_S1 / 4 + lane + 64 * i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < VW_S2 / 4 / 64; ++i) t2[lane + 64 * i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
-#pragma unroll
-    for (int i = VW_S2 / 4 / 64; i < VW_S2 / 64; ++i) t2[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < (VW_S2 + 63) / 64; ++i) {     // key2 (VW_S2 / 4 vectors of EMPTY), then ded and best (zero)
+      const uint32_t e = lane + 64 * i;
+      if (e < VW_S2) t2[e] = e < VW_S2 / 4 ? make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY) : make_uint4(0, 0, 0, 0);
+    }
   };
   if (a < b) {
     clear();
@@ -3134,8 +3136,15 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
             uint2* heavy = (uint2*)(tile_start + ((nt + 2 + 1) & ~1u));   // 8-byte aligned
             uint32_t* heavy_q = (uint32_t*)(heavy + hcap);
             hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)nt + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start, n_heavy);
-            hipLaunchKernelGGL(vt_stream_kernel, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                               (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
+            // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
+            const int slb_ = pl.g_lo - 1 - mbp.dbits;
+            const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(t->max_sid, 1u));
+            if ((double)(1u << slb_) + 64.0 / per_song <= 40.0)
+              hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
+            else
+              hipLaunchKernelGGL(vt_stream_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
             hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
                                dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
                                (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
