@@ -2768,7 +2768,14 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   ctx->st_rows = ctx->st_pairs = ctx->st_keys = 0;
   const uint64_t P_BUDGET = 1ull << 28;     // votes of one vote pass (its buffers: 2 x 4 or 8 bytes per vote)
-  const uint64_t SUB_BUDGET = 1ull << 30;   // votes of one sub-batch of queries (one head: compose, sort, probe, one round trip)
+  // votes of one sub-batch of queries (one head: compose, sort, probe, one round trip): up to 2^30 where the device has
+  // the memory for it (a sub-batch that ends up on the 8-byte path needs ~32 bytes per vote of workspace)
+  uint64_t SUB_BUDGET = P_BUDGET;
+  if (n_queries > 32) {
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+      SUB_BUDGET = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(P_BUDGET, (uint64_t)mem_free / 64));
+  }
   // segment descriptors for the kernels (an empty table probes one empty segment)
   std::vector<shz_seg_dev> hsegs;
   for (const shz_seg& g : all_segs(t)) hsegs.push_back(shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets});
