@@ -245,8 +245,9 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
 
 def single_query_latency(ctx, tbl, rank, nc, n_samples, n_iter=60):
     """p50 / p99 of ONE 5 s query: fingerprint (host int16 in) + match (top-2) per call, against the step's table."""
-    from oracle import synth   # input generator only
-    q = synth.synth_clip(1234, rank * nc + 7, n_samples, 0, 8000)[13 * 2048 + 77:13 * 2048 + 77 + 5 * FS]
+    track = ctx.synth_pcm(1234, rank * nc + 7, 1, n_samples, 0, 8000)   # the step's track 7, synthesised on the device
+    q = track.download(np.int16, n_samples)[13 * 2048 + 77:13 * 2048 + 77 + 5 * FS].copy()
+    track.free()
     qoff = np.array([0, len(q)], np.uint64)
     lat = {"fingerprint": [], "match": [], "total": []}
     top = None

@@ -7,7 +7,6 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import shazam_amd as S  # noqa: E402
-from oracle import synth  # noqa: E402  (input generator only)
 
 songs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 ctx = S.get_context(0)
@@ -23,7 +22,8 @@ for c0 in range(0, songs, 500):
                                 "fingerprinted": 1, "date_created": None}
     db.insert_clips(k, t1, ho, c0 + 1)
 db.finalize()
-q = synth.synth_clip(4321, 7, n, 4000, 1500)[13 * 2048 + 77:13 * 2048 + 77 + 5 * 44100]
+_trk = ctx.synth_pcm(4321, 7, 1, n, 4000, 1500)
+q = _trk.download(np.int16, n)[13 * 2048 + 77:13 * 2048 + 77 + 5 * 44100].copy()
 for _ in range(3):
     S.recognize(q, db=db)
 lat = {"fingerprint": [], "match": [], "total": []}

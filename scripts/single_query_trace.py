@@ -7,7 +7,6 @@ import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from shazam_amd import _ffi, Table  # noqa: E402
-from oracle import synth  # noqa: E402  (input generator only)
 
 songs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -21,7 +20,8 @@ for c0 in range(0, songs, 1000):
     pcm.free()
     tbl.insert_clips(k, t1, ho, sid0=1 + c0)
 tbl.finalize()
-q = synth.synth_clip(1234, 7, n, 0, 8000)[13 * 2048 + 77:13 * 2048 + 77 + 5 * 44100]
+_trk = ctx.synth_pcm(1234, 7, 1, n, 0, 8000)
+q = _trk.download(np.int16, n)[13 * 2048 + 77:13 * 2048 + 77 + 5 * 44100].copy()
 qoff = np.array([0, len(q)], np.uint64)
 lat = []
 for i in range(iters):
