@@ -39,6 +39,8 @@ extern "C" {
 #define SHZ_OUT_DEVICE 2u    /* output pointers are device memory              */
 #define SHZ_IN_DEVICE 4u     /* generic: input arrays are device memory        */
 #define SHZ_STFT_POWER 8u    /* shz_stft_db: write the PSD itself, not 10*log10 */
+#define SHZ_MATCH_FULL_SORT 16u /* shz_match_batch: 8-byte votes, full radix sort and record chain (the reference form of
+                                  the vote: what the 4-byte votes and the vote tiles must reproduce) */
 
 /* constants of the algorithm: __init__.py:41-51 == recognizer.py:21-38 */
 #define SHZ_NFFT 4096

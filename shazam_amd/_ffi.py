@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHZ_LIB") or os.path.join(_HERE, "libshz.so")  # SHZ_LIB: A/B builds of the same ABI
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
-PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER = 1, 2, 4, 8
+PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER, MATCH_FULL_SORT = 1, 2, 4, 8, 16
 NFFT, HOP, NBINS = 4096, 2048, 2049
 
 u8p, u16p, u32p, i32p, u64p, i16p, f64p = (C.POINTER(t) for t in (
@@ -500,8 +500,9 @@ class Table:
         self.ctx.check(lib().shz_table_allgather(self.h, comm.h, C.byref(b)))
         return b.value
 
-    def match(self, key32, q_off, query_off, topn=2):
-        """Batched return_matches + align_matches.  Returns dict of arrays (see shz.h)."""
+    def match(self, key32, q_off, query_off, topn=2, full_sort=False):
+        """Batched return_matches + align_matches.  Returns dict of arrays (see shz.h).  full_sort: the vote as one
+        sort of 8-byte votes + record chain (SHZ_MATCH_FULL_SORT), the form the faster vote paths are tested against."""
         k = np.ascontiguousarray(key32, np.uint32)
         o = np.ascontiguousarray(q_off, np.uint32)
         qo = np.ascontiguousarray(query_off, np.uint64)
@@ -510,7 +511,8 @@ class Table:
             "sid": np.zeros((nq, topn), np.uint32), "delta": np.zeros((nq, topn), np.int32),
             "aligned": np.zeros((nq, topn), np.uint32), "dedup": np.zeros((nq, topn), np.uint32),
             "nres": np.zeros(nq, np.uint32), "nhash": np.zeros(nq, np.uint32), "npairs": np.zeros(nq, np.uint64)}
-        self.ctx.check(lib().shz_match_batch(self.ctx.h, self.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, topn, 0,
+        self.ctx.check(lib().shz_match_batch(self.ctx.h, self.h, ptr(k), ptr(o), qo.ctypes.data_as(u64p), nq, topn,
+                                             MATCH_FULL_SORT if full_sort else 0,
                                              ptr(res["sid"]), ptr(res["delta"]), ptr(res["aligned"]), ptr(res["dedup"]),
                                              ptr(res["nres"]), ptr(res["nhash"]), ptr(res["npairs"])))
         return res

@@ -3009,7 +3009,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       std::vector<vpass> passes;
       const int qbits32 = 31 - mb.sb - mb.dbits;
       static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
-      bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0;
+      bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0 && !(flags & SHZ_MATCH_FULL_SORT);
       // vote tiles (vt_fold_kernel): two radix passes + an LDS fold per tile instead of four passes + the record chain
       static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
       const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS;
@@ -3030,7 +3030,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       // ONE query with few votes (a 5-10 s query against thousands of songs): expand, then one workgroup folds the
       // unordered votes (vt_fold_kernel over the single range [0, P)) -- 5 launches instead of the 9 of sort + fold,
       // and the launches are what such a match costs
-      const bool one_wg = !use32 && nq == 1 && P <= VT_ONE_WG_MAX && qbits32 >= 0 && tiles_env != 0 && topn <= VT_MAXTOPN &&
+      const bool one_wg = !use32 && !(flags & SHZ_MATCH_FULL_SORT) && nq == 1 && P <= VT_ONE_WG_MAX && qbits32 >= 0 && tiles_env != 0 && topn <= VT_MAXTOPN &&
                           mb.dbits <= VT_MAX_DBITS;
       uint64_t pmax = 0;
       for (const vpass& vp : passes) pmax = std::max(pmax, vp.v_hi - vp.v_lo);

@@ -130,3 +130,32 @@ def test_many_results_over_several_passes():
     base = _run("topn20", 0, 0)
     assert int(base[1]) > 40 * 32768, "two-level top-n needs more than 32,768 votes per query"
     assert _run("topn20", 1, None) == base
+
+
+def test_vote_paths_agree_at_200k_songs():
+    """One table of 200,000 x 30 s tracks (2.3e9 rows), 300 ten-second queries at 10 dB SNR and 60 at 0 dB in batches,
+    plus single queries: the shipped vote path (segmented 4-byte passes, vote tiles) against the full sort of 8-byte
+    votes (SHZ_MATCH_FULL_SORT) in the same process, every output array."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench_db
+    from shazam_amd import _ffi
+    ctx = _ffi.Context(0)
+    songs, n, qn = 200000, 30 * 44100, 10 * 44100
+    tbl, _stats, bufs = bench_db.build_table(ctx, songs, 30.0, 1000, finalize_every=100000)
+    for b in bufs[:2]:
+        b.free()
+    rng = np.random.default_rng(21)
+    for nq, snr, topn in ((300, 10.0, 2), (60, 0.0, 5), (1, 10.0, 8), (1, 0.0, 1)):
+        tids = rng.integers(0, songs, nq)
+        starts = rng.integers(0, n - qn, nq)
+        q, qb = bench_db.make_queries(ctx, tids, starts, qn, snr)
+        k, t1, ho, _ = ctx.fingerprint_batch(q, np.arange(nq + 1, dtype=np.uint64) * qn, fs=44100, pcm_device=True)
+        fast = tbl.match(k, t1, ho, topn)
+        full = tbl.match(k, t1, ho, topn, full_sort=True)
+        for name in sorted(full):
+            assert np.array_equal(fast[name], full[name]), (nq, snr, name)
+        if snr >= 10.0:
+            assert (fast["sid"][:, 0] == 1 + tids).mean() > 0.97
+        for b in {id(b): b for b in qb}.values():
+            b.free()
