@@ -103,6 +103,12 @@ int32_t shz_sort_pairs(shz_ctx* ctx, uint64_t* keys, void* vals, uint32_t val_by
 int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, uint64_t add,
                         uint64_t* out64);
 
+/* The SEGMENTED form behind the vote passes (tests / tools): segment i = keys [seg_off[i], seg_off[i+1]), n_segs <= 128;
+ * every segment is ordered (stably) among its own keys on bits [bit_lo, bit_hi), no key leaves its segment.
+ * keys / seg_off / out are HOST arrays; seg_off[0] = 0, seg_off[n_segs] = n < 2^32. */
+int32_t shz_sort_keys32_seg(shz_ctx* ctx, const uint32_t* keys, const uint64_t* seg_off, uint32_t n_segs, uint32_t bit_lo,
+                            uint32_t bit_hi, uint32_t* out);
+
 /* Query preparation (bench / tests): exact sum of squares of each clip (device PCM, clip-major, equal
  * lengths) to HOST, and out = clip(rint(sig + scale[c] * noise)) on the device: the digital form of
  * get_noise_from_sound + sf.write (recognizer_test.py:426-435, 557); twin: oracle/synth.mix_query. */

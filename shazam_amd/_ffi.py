@@ -42,6 +42,7 @@ SIGNATURES = {
     "shz_membw": (C.c_int32, [vp, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
     "shz_sort_pairs": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),
     "shz_sort_keys32": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
+    "shz_sort_keys32_seg": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
@@ -210,6 +211,15 @@ class Context:
         k = np.ascontiguousarray(keys, np.uint32)
         out = np.empty(len(k), np.uint64)
         self.check(lib().shz_sort_keys32(self.h, ptr(k), len(k), int(bit_lo), int(bit_hi), int(add), ptr(out)))
+        return out
+
+    def sort_keys32_seg(self, keys: np.ndarray, seg_off, bit_lo: int = 0, bit_hi: int = 32) -> np.ndarray:
+        """Segmented stable device radix sort of uint32 keys on bits [bit_lo, bit_hi): segment i = keys[seg_off[i] : seg_off[i + 1]]
+        is ordered among itself (the vote passes: one segment per query)."""
+        k = np.ascontiguousarray(keys, np.uint32)
+        so = np.ascontiguousarray(seg_off, np.uint64)
+        out = np.empty(len(k), np.uint32)
+        self.check(lib().shz_sort_keys32_seg(self.h, ptr(k), so.ctypes.data_as(u64p), len(so) - 1, int(bit_lo), int(bit_hi), ptr(out)))
         return out
 
     def sort_pairs(self, keys: np.ndarray, vals=None, bit_lo: int = 0, bit_hi: int = 64):

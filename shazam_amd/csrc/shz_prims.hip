@@ -807,6 +807,34 @@ int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, i
   return SHZ_OK;
 }
 
+extern "C" int32_t shz_sort_keys32_seg(shz_ctx* ctx, const uint32_t* keys, const uint64_t* seg_off, uint32_t n_segs,
+                                       uint32_t bit_lo, uint32_t bit_hi, uint32_t* out) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (!seg_off || n_segs == 0 || n_segs > SHZ_SEG_MAX) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32_seg: 1..%d segments", SHZ_SEG_MAX);
+  const uint64_t n = seg_off[n_segs];
+  if (n == 0) return SHZ_OK;
+  if (!keys || !out || seg_off[0] != 0 || n >= (1ull << 32) || bit_hi > 32 || bit_lo > bit_hi)
+    SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32_seg: arguments");
+  shz_seg_plan sp;
+  sp.nq = n_segs;
+  sp.qv[0] = sp.bq[0] = 0;
+  for (uint32_t i = 0; i < SHZ_SEG_MAX; ++i) {
+    const uint64_t a = i < n_segs ? seg_off[i] : n, b = i < n_segs ? seg_off[i + 1] : n;
+    if (b < a) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32_seg: offsets must not decrease");
+    sp.qv[i + 1] = (uint32_t)b;
+    sp.bq[i + 1] = sp.bq[i] + (uint32_t)((b - a + SORT_TILE - 1) / SORT_TILE);
+  }
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  void* k0;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
+  int sel = 0;
+  SHZ_TRY(shz_sort_u32_seg(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, n, (int)bit_lo, (int)bit_hi, sp, &sel));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out, (uint32_t*)k0 + (sel ? n : 0), n * 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
                                    uint64_t add, uint64_t* out64) {
   if (!ctx) return SHZ_E_INVALID;

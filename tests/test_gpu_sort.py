@@ -67,3 +67,26 @@ def test_sort_keys32_against_numpy(n, bits):
     field = (k >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1) if hi > lo else np.zeros(n, np.uint32)
     want = k[np.argsort(field, kind="stable")].astype(np.uint64) + np.uint64(add)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("sizes", [[1], [5, 0, 7], [4096, 4097, 1, 0, 0, 12289], [3, 70001, 2, 4095, 64, 64, 8193],
+                                   [1000] * 128, [0, 0, 9], [300017]])
+@pytest.mark.parametrize("bits", [(15, 31), (0, 8), (11, 27), (3, 32), (14, 32)])
+def test_segmented_sort32(sizes, bits):
+    """shz_sort_u32_seg (the vote passes): every segment ordered among its own keys, stably, on the given bits; segments of
+    any length (empty, one key, not a multiple of four: their blocks start at unaligned addresses)."""
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    rng = np.random.default_rng(sum(sizes) * 31 + bits[0])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(off[-1])
+    keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    if n > 100:
+        keys[n // 2: n // 2 + n // 5] = keys[n // 2]          # a long run of one key
+    lo, hi = bits
+    got = ctx.sort_keys32_seg(keys, off, lo, hi)
+    mask = np.uint32((((1 << (hi - lo)) - 1) << lo) & 0xFFFFFFFF)
+    for i in range(len(sizes)):
+        seg = keys[int(off[i]):int(off[i + 1])]
+        order = np.argsort((seg & mask) >> np.uint32(lo), kind="stable")
+        assert np.array_equal(got[int(off[i]):int(off[i + 1])], seg[order]), (i, sizes[i])
