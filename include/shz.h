@@ -208,6 +208,8 @@ int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, uint64_t n_si
 /* DROP TABLE fingerprints: no rows, no segments; allocations of the active segment are kept for the rows to come. */
 int32_t shz_table_clear(shz_table* t);
 int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged);
+/* number of sorted segments the finalized rows live in (every query hash is looked up in each of them) */
+int32_t shz_table_segments(shz_table* t, uint32_t* n_segments);
 /* sorted rows to host (dump / parity): arrays of cap rows */
 int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid, uint32_t* off, uint64_t cap, uint64_t* count);
 /* SELECT hash, song_id, offset WHERE hash IN (keys) (SELECT_MULTIPLE, mysql_database.py:82-86;

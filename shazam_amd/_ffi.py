@@ -62,6 +62,7 @@ SIGNATURES = {
     "shz_table_finalize": (C.c_int32, [vp]),
     "shz_table_set_segment_rows": (C.c_int32, [vp, C.c_uint64]),
     "shz_table_rows": (C.c_int32, [vp, u64p, u64p]),
+    "shz_table_segments": (C.c_int32, [vp, vp]),
     "shz_table_delete_songs": (C.c_int32, [vp, vp, C.c_uint64, u64p]),
     "shz_table_clear": (C.c_int32, [vp]),
     "shz_table_export": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, u64p]),
@@ -468,6 +469,11 @@ class Table:
         a, b = C.c_uint64(), C.c_uint64()
         self.ctx.check(lib().shz_table_rows(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def segments(self) -> int:
+        n = C.c_uint32()
+        self.ctx.check(lib().shz_table_segments(self.h, C.byref(n)))
+        return n.value
 
     def export(self):
         n, _ = self.rows()

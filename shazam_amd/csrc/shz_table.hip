@@ -843,6 +843,12 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   return SHZ_OK;
 }
 
+extern "C" int32_t shz_table_segments(shz_table* t, uint32_t* n_segments) {
+  if (!t || !n_segments) return SHZ_E_INVALID;
+  *n_segments = (uint32_t)t->done.size() + (t->n ? 1u : 0u);
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_table_set_segment_rows(shz_table* t, uint64_t rows) {
   if (!t) return SHZ_E_INVALID;
   if (rows < 16 || rows >= (1ull << 32)) SHZ_FAIL(t->ctx, SHZ_E_INVALID, "segment rows must be in [16, 2^32)");

@@ -152,3 +152,31 @@ def test_sharded_table_delete(env):
     assert st.rows()[0] == t.rows()[0] == len({r for r in _triples(k, s, o) if r[1] not in (4, 5, 6)})
     st.close()
     t.close()
+
+
+def test_segments_are_topped_up_before_they_freeze(env):
+    """Batches of 0.55 x the segment limit: the active segment takes the slices (by key) of the next batch that still fit
+    before it is frozen, so 12 batches end in ~7 segments of ~limit rows, not in 12 half-empty ones -- and the rows are
+    exactly the union of the batches (duplicates across batches included)."""
+    S, F, ctx = env
+    rng = np.random.default_rng(17)
+    limit, per = 20000, 11000
+    t = F.Table(ctx)
+    t.set_segment_rows(limit)
+    want = set()
+    prev = None
+    for i in range(12):
+        k, s, o = _rows(rng, per, nsid=4000)
+        t.insert(k, s, o)
+        if prev is not None:                     # part of the previous batch again: some of it sits in a frozen segment
+            t.insert(prev[0][::7], prev[1][::7], prev[2][::7])
+        t.finalize()
+        want |= _triples(k, s, o)
+        prev = (k, s, o)
+    k, s, o = t.export()
+    assert len(k) == len(want) and _triples(k, s, o) == want
+    assert t.segments() <= -(-len(want) // limit) + 2, t.segments()
+    # a query still finds every copy: lookup of a key that went into different segments
+    probe = np.unique(k[:200])
+    lk, ls, lo = t.lookup(probe)
+    assert _triples(lk, ls, lo) == {x for x in want if x[0] in set(probe.tolist())}
