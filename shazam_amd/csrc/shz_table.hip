@@ -1386,12 +1386,13 @@ __device__ __forceinline__ uint32_t mh_block_scan(uint32_t v, uint32_t* total, u
 }
 
 // Stable LSD radix sort of m <= MH_MAX keys that sit in sk[0], on bits [bit_lo, bit_hi), 8 bits per pass, all in LDS.
-// Wave w owns the slice [w * 512, w * 512 + 512): every pass ranks a slice's elements among themselves by ballots
+// Wave w owns the slice [w * 64 rows, (w + 1) * 64 rows), rows = ceil(m / 1024): every pass ranks a slice's elements among themselves by ballots
 // (the scheme of sort_scatter_kernel), prefixes the per-wave digit counts over the waves and the digits, and scatters
 // into the other buffer.  Passes over digits on which no two keys differ (`diff` = OR of all keys ^ AND of all keys)
 // are skipped.  Returns the index of the buffer that holds the result.  Ends with a barrier.
 __device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wrun)[256], uint32_t* dbase, uint32_t m,
                                            int bit_lo, int bit_hi, unsigned long long diff) {
+  const int rows = (int)((m + MH_THREADS - 1) / MH_THREADS);   // rows of 64 elements per wave: the slices shrink with m
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   int cur = 0;
@@ -1404,7 +1405,8 @@ __device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wr
     uint32_t rank[MH_ROWS];
 #pragma unroll
     for (int r = 0; r < MH_ROWS; ++r) {
-      const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+      if (r >= rows) break;   // uniform
+      const uint32_t li = (uint32_t)wave * (rows * 64) + (uint32_t)r * 64 + lane;
       const bool valid = li < m;
       k[r] = valid ? sk[cur][li] : 0;
       const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
@@ -1448,7 +1450,8 @@ __device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wr
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < MH_ROWS; ++r) {
-      const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+      if (r >= rows) break;   // uniform
+      const uint32_t li = (uint32_t)wave * (rows * 64) + (uint32_t)r * 64 + lane;
       if (li < m) {
         const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
         sk[cur ^ 1][dbase[d] + wrun[wave][d] + rank[r]] = k[r];
@@ -1482,7 +1485,7 @@ __global__ __launch_bounds__(MH_THREADS) void m_head_small_kernel(const uint32_t
   __shared__ uint32_t dbase[256], tmp[20];
   __shared__ unsigned long long s_or, s_and;
   __shared__ uint32_t s_omax;
-  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int j = threadIdx.x, lane = j & 63;
   if (j == 0) { s_or = 0; s_and = ~0ull; s_omax = 0; }
   __syncthreads();
   // compose (query, key, offset) elements; wave w owns the slice [w * 512, w * 512 + 512)
@@ -1491,7 +1494,7 @@ __global__ __launch_bounds__(MH_THREADS) void m_head_small_kernel(const uint32_t
   uint32_t omax = 0;
 #pragma unroll
   for (int r = 0; r < MH_ROWS; ++r) {
-    const uint32_t li = (uint32_t)wave * (MH_ROWS * 64) + (uint32_t)r * 64 + lane;
+    const uint32_t li = (uint32_t)r * MH_THREADS + j;   // (any order: the sort follows)
     if (li < m) {
       const uint64_t h = h0 + li;
       const uint32_t o = q_off[h];
