@@ -867,6 +867,7 @@ extern "C" uint32_t shz_frame_count(uint64_t n) {
 
 #define PK_SEG 252       // output frames per peak_pick workgroup (12 blocks of 21) when workgroups are scarce
 #define PK_SEG_LONG 672  // ... and when the batch is large: 32 blocks, a 30 s clip in one piece (no time halo)
+#define PK_SEG_SHORT 42  // ... and when a handful of workgroups is all there is: 2 blocks
 
 static const mask_geom MG_F64 = {(SHZ_NBINS + PK_SW - 1) / PK_SW, 4, 63, PK_SW};
 static mask_geom mg_f32(int nw) {
@@ -936,7 +937,9 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
   // Each segment re-reads 10 halo frames on both sides (PMC: -4.6 % kernel time with whole-clip segments), but short
   // segments keep the chip busy on small batches: go long once that still leaves >= 4 workgroups per slot.
   const uint64_t slots = (uint64_t)ctx->prop.multiProcessorCount * wg_per_cu;
-  const uint32_t seg_len = (uint64_t)sb.frames * n_slabs / PK_SEG_LONG >= 4 * slots ? PK_SEG_LONG : PK_SEG;
+  // A single short clip (one 5 s query: 107 frames) is all latency: 42-frame segments halve the rows a workgroup walks.
+  const uint32_t seg_len = (uint64_t)sb.frames * n_slabs / PK_SEG_LONG >= 4 * slots ? PK_SEG_LONG
+                           : (uint64_t)sb.frames * n_slabs / PK_SEG * 8 < slots ? PK_SEG_SHORT : PK_SEG;
   // one blob: soff[nc] | len[nc] | foff[nc+1] (u32, padded to 8) | segs
   const uint64_t foff_words = (nc + 2) / 2;  // u64 words holding nc+1 u32
   for (uint32_t i = 0; i < nc; ++i) {
