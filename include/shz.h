@@ -257,6 +257,13 @@ int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_rows, uint32_t
 /* seconds the last shz_table_allgather / shz_table_finalize_runs spent sorting its own rows, exchanging, merging
  * the runs and cutting segments (host clock around stream syncs).  Any pointer may be NULL. */
 int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, double* merge_s, double* segments_s);
+/* Host seconds the table spent per phase of the build since the last reset (stream drained at each phase border):
+ * staging allocation, insert, INSERT-IGNORE anti-join against frozen segments, segment top-up, maxima, sort, merge,
+ * unique + scan, column allocation, compaction into columns, bucket index, slicing, release of the staging columns.
+ * The reference's analogue is the per-file wall time of fingerprint_directory's insert loop (__init__.py:378-386).
+ * seconds: host array of cap entries (may be NULL); *n = number of phases; shz_table_phase_name(i) names phase i. */
+int32_t shz_table_phase_stats(shz_table* t, double* seconds, uint32_t cap, uint32_t* n, int32_t reset);
+const char* shz_table_phase_name(uint32_t i);
 int32_t shz_comm_barrier(shz_comm* c);
 
 /* ---- key-sharded table (new; SURVEY.md 8f row 4: the table no longer fits one GPU) -------

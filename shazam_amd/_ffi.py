@@ -78,6 +78,8 @@ SIGNATURES = {
     "shz_table_finalize_runs": (C.c_int32, [vp, u64p, C.c_uint32]),
     "shz_table_build_stats": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
+    "shz_table_phase_stats": (C.c_int32, [vp, C.POINTER(C.c_double), C.c_uint32, u32p, C.c_int32]),
+    "shz_table_phase_name": (C.c_char_p, [C.c_uint32]),
     "shz_comm_barrier": (C.c_int32, [vp]),
     "shz_shard_of_keys": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp]),
     "shz_table_keep_shard": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
@@ -510,6 +512,14 @@ class Table:
         v = [C.c_double() for _ in range(4)]
         self.ctx.check(lib().shz_table_build_stats(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("sort_s", "exchange_s", "merge_s", "segments_s"), (float(x.value) for x in v)))
+
+    def phase_stats(self, reset=False) -> dict:
+        """Host seconds per build phase since the last reset (shz_table_phase_stats)."""
+        n = C.c_uint32()
+        self.ctx.check(lib().shz_table_phase_stats(self.h, None, 0, C.byref(n), 0))
+        v = (C.c_double * n.value)()
+        self.ctx.check(lib().shz_table_phase_stats(self.h, v, n.value, C.byref(n), 1 if reset else 0))
+        return {lib().shz_table_phase_name(i).decode(): float(v[i]) for i in range(n.value)}
 
     def allgather(self, comm: "Comm") -> int:
         b = C.c_uint64()

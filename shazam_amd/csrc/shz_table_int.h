@@ -1,0 +1,102 @@
+// Internal to libshz.so: the fingerprint table as the build side (shz_build.hip) and the match side (shz_table.hip)
+// both see it.  Not part of the ABI.
+#pragma once
+#include <time.h>
+
+#include <algorithm>
+
+#include "shz_internal.h"
+
+// A table is a list of immutable sorted SEGMENTS (each < 2^32 rows, its own bucket index) plus the
+// active segment below that new rows are merged into; a probe visits every segment.  Segments lift
+// the 2^32-row limit of one radix sort (BASELINE config 3: 7.1e9 rows = 85 GB fits one GPU's HBM).
+struct shz_seg {
+  uint32_t *key, *sid, *off, *bucket;
+  uint64_t n, nbuckets;
+};
+struct shz_seg_dev {  // what the match kernels see
+  const uint32_t *key, *sid, *off, *bucket;
+  uint32_t n;
+  uint64_t nbuckets;
+};
+#define SHZ_MAX_SEGS 32
+
+#define SHZ_TABLE_PHASES 16
+struct shz_table {
+  shz_ctx* ctx = nullptr;
+  std::vector<shz_seg> done;           // frozen segments
+  uint64_t seg_limit = 1ull << 31;     // rows per segment (bounds the sort scratch: 16 B/row)
+  uint32_t *key = nullptr, *sid = nullptr, *off = nullptr;   // active segment
+  uint64_t n = 0;
+  uint64_t cap = 0, bcap = 0;  // rows the active columns / entries the bucket array can hold (reused across finalize calls)
+  uint32_t *skey = nullptr, *ssid = nullptr, *soff = nullptr;
+  uint64_t ns = 0, scap = 0;
+  uint32_t* bucket = nullptr;
+  uint64_t nbuckets = 0;  // bucket has nbuckets+1 entries
+  uint32_t max_sid = 0, max_off = 0;
+  double bs_sort = 0, bs_exchange = 0, bs_merge = 0, bs_segments = 0;   // seconds of the last run-merge build
+  bool broken = false;  // a finalize ran out of memory after giving up the old columns: rows were lost, refuse further use
+  double ph[SHZ_TABLE_PHASES] = {0};   // host seconds per build phase since the last reset (shz_table_phase_stats)
+};
+
+// phases of the single-GPU build, in the order shz_table_phase_stats reports them
+enum { PH_STAGE_ALLOC = 0, PH_INSERT, PH_DEDUP_FROZEN, PH_TOPUP, PH_MAXES, PH_SORT, PH_MERGE, PH_UNIQ, PH_COL_ALLOC, PH_COMPACT,
+       PH_BUCKET, PH_SLICE, PH_STAGE_FREE };
+static_assert(PH_STAGE_FREE < SHZ_TABLE_PHASES, "phase table too small");
+static inline double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+// a phase ends here: the stream is drained so that the host clock sees the kernels of the phase
+struct ph_clock {
+  shz_table* t;
+  double t0;
+  explicit ph_clock(shz_table* t_) : t(t_), t0(now_s()) {}
+  void lap(int which) {
+    (void)hipStreamSynchronize(t->ctx->stream);
+    const double t1 = now_s();
+    t->ph[which] += t1 - t0;
+    t0 = t1;
+  }
+  void skip() { t0 = now_s(); }
+};
+
+static inline std::vector<shz_seg> all_segs(const shz_table* t) {
+  std::vector<shz_seg> v = t->done;
+  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
+  return v;
+}
+static inline uint64_t total_rows(const shz_table* t) {
+  uint64_t n = t->n;
+  for (const shz_seg& g : t->done) n += g.n;
+  return n;
+}
+
+static inline int bits_for(uint64_t v) {
+  int b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b ? b : 1;
+}
+
+// device allocations of one call: freed when the call leaves early (SHZ_TRY / SHZ_FAIL return), handed over with take()
+struct dev_cols {
+  uint32_t* p[3] = {nullptr, nullptr, nullptr};
+  ~dev_cols() {
+    for (uint32_t* q : p)
+      if (q) (void)hipFree(q);
+  }
+  bool alloc(uint64_t rows) {
+    for (auto& q : p)
+      if (hipMalloc(&q, std::max<uint64_t>(rows, 1) * 4) != hipSuccess) return false;
+    return true;
+  }
+  uint32_t* take(int i) { uint32_t* q = p[i]; p[i] = nullptr; return q; }
+};
+
+static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+// shard of a key: a different multiplier and bit field than slice_of (segments inside a shard stay balanced)
+__host__ __device__ __forceinline__ uint32_t shard_of(uint32_t key, uint32_t nshards) {
+  return (((key ^ (key >> 15)) * 0x85EBCA6Bu) >> 10) % nshards;
+}

@@ -39,7 +39,7 @@ def merge_rows(parts):
 
 def pack_rows(key32, sid, off, sid_bits: int, off_bits: int) -> np.ndarray:
     """key << (sid_bits + off_bits) | sid << off_bits | off: the 8-byte form in which rows are sorted, travel between
-    the ranks and are merged (csrc/shz_table.hip: tbl_compose1_kernel); its numeric order is the table's order."""
+    the ranks and are merged (csrc/shz_build.hip: tbl_compose1_kernel); its numeric order is the table's order."""
     return ((np.asarray(key32, np.uint64) << np.uint64(sid_bits + off_bits)) | (np.asarray(sid, np.uint64) << np.uint64(off_bits))
             | np.asarray(off, np.uint64))
 

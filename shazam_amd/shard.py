@@ -33,7 +33,7 @@ def shard_of_keys(key32, nshards: int) -> np.ndarray:
 
 
 def shard_of_keys_numpy(key32, nshards: int) -> np.ndarray:
-    """numpy twin of ``shard_of`` in shz_table.hip (used by the CPU tests to pin the function)."""
+    """numpy twin of ``shard_of`` in shz_table_int.h (used by the CPU tests to pin the function)."""
     k = np.asarray(key32, np.uint32)
     h = ((k ^ (k >> np.uint32(15))).astype(np.uint64) * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
     return ((h >> np.uint64(10)) % np.uint64(nshards)).astype(np.uint32)
