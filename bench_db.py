@@ -28,10 +28,14 @@ FS = 44100
 SEED_TRACKS, SEED_NOISE = 4321, 777
 
 
+ROWS_PER_FRAME_HINT = 18.5   # hashes per frame of the synthetic corpora (17.6-18.7 measured): sizes shz_table_reserve
+
+
 def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1500, finalize_every=0, shards=1,
-                progress=None):
+                progress=None, reserve=True):
     """Synthesise `songs` tracks on the device, fingerprint them in chunks and build one HBM table.
-    Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
+    Every `finalize_every` songs the staged rows are sealed into a sorted run (bounded staging and sort scratch; rows become
+    visible at the final finalize).  Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
     from shazam_amd import _ffi, Table
     n_samples = int(round(seconds * FS))
     frames = int(_ffi.lib().shz_frame_count(n_samples))
@@ -40,6 +44,9 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
         tbl = ShardedTable(ctx, nshards=shards)
     else:
         tbl = Table(ctx)
+        if reserve:   # the table's arenas in one go, allocated beside the first fingerprint batches
+            per_batch = finalize_every if finalize_every else songs
+            tbl.reserve(int(songs * frames * ROWS_PER_FRAME_HINT), int(min(per_batch, songs) * frames * ROWS_PER_FRAME_HINT))
     cap = chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
     pcm = ctx.alloc(chunk * n_samples * 2)
@@ -61,7 +68,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
         n_rows_in += cnt
         if finalize_every and (c0 + nc) % finalize_every == 0 and c0 + nc < songs:
             t0 = time.perf_counter()
-            tbl.finalize()        # bounds staged rows + sort scratch; a full active segment is frozen
+            tbl.seal_run()        # bounds staged rows + sort scratch; full segments are cut as soon as enough rows wait
             ctx.sync()
             t_fin += time.perf_counter() - t0
             if progress:
@@ -75,7 +82,8 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     pcm.free()
     stats = {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
              "rows_inserted": int(n_rows_in), "rows": int(rows), "songs_per_s": songs / t_build,
-             "audio_s_per_s": songs * seconds / t_build}
+             "audio_s_per_s": songs * seconds / t_build, "segments": int(tbl.segments()) if shards == 1 else None,
+             "phases_s": {k: round(v, 4) for k, v in tbl.phase_stats().items() if v > 5e-4} if shards == 1 else None}
     return tbl, stats, (kbuf, tbuf, cap)
 
 

@@ -39,6 +39,7 @@ extern "C" {
 #define SHZ_OUT_DEVICE 2u    /* output pointers are device memory              */
 #define SHZ_IN_DEVICE 4u     /* generic: input arrays are device memory        */
 #define SHZ_STFT_POWER 8u    /* shz_stft_db: write the PSD itself, not 10*log10 */
+#define SHZ_RESERVE_GATHER 32u /* shz_table_reserve: size the run arena for an all-gathered build (every rank's rows) */
 #define SHZ_MATCH_FULL_SORT 16u /* shz_match_batch: 8-byte votes, full radix sort and record chain (the reference form of
                                   the vote: what the 4-byte votes and the vote tiles must reproduce) */
 
@@ -62,6 +63,8 @@ const char* shz_version(void);
 /* name: >=128 bytes; any out pointer may be NULL */
 int32_t shz_device_info(shz_ctx* ctx, char* name, uint64_t name_cap, uint64_t* hbm_bytes,
                         int32_t* compute_units, int32_t* clock_khz);
+/* device memory free / total right now (hipMemGetInfo): sizes reservations, shows leaks in tests */
+int32_t shz_mem_info(shz_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int32_t shz_dev_alloc(shz_ctx* ctx, uint64_t bytes, void** dptr);
 int32_t shz_dev_free(shz_ctx* ctx, void* dptr);
 int32_t shz_copy_h2d(shz_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
@@ -196,6 +199,17 @@ int32_t shz_table_insert_clips(shz_table* t, const uint32_t* key32, const uint32
                                uint32_t n_clips, uint32_t sid0, uint32_t flags);
 /* sort staged+existing rows by (key, sid, off), drop duplicates, build the bucket index */
 int32_t shz_table_finalize(shz_table* t);
+/* Bulk build (the insert loop of fingerprint_directory, __init__.py:378-386, at database scale):
+ * shz_table_reserve announces how many rows the table will hold and how many arrive between two seals; ONE slab for
+ * the segments' columns, the run arena, the staging columns and the sort scratch are then allocated once, on a helper
+ * thread beside the first fingerprint batches, and the build performs no further device allocation.  Without it
+ * everything still works, allocating as it goes.  rows_hint = 0: no-op.  flags: SHZ_RESERVE_GATHER.
+ * shz_table_seal_run turns the staged rows into a sorted run (bounded scratch: one batch) WITHOUT making them visible
+ * to queries; full segments are cut as soon as enough rows wait; shz_table_finalize merges what is left (k-way merge of
+ * the runs, 8 bytes read + 12 written per row) and makes everything visible.  On a table whose active segment holds
+ * rows, or whose song ids + offsets need more than 32 bits, seal_run is finalize. */
+int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t batch_rows_hint, uint32_t flags);
+int32_t shz_table_seal_run(shz_table* t);
 /* A table is a list of sorted segments (each one radix sort, < 2^32 rows) that every probe visits; rows
  * beyond `rows` per segment open a new one at finalize.  Default 2^31; smaller values only for tests.
  * UNIQUE(song_id, offset, hash) + INSERT IGNORE (mysql_database.py:54-55, 62-68) hold across segments: staged rows

@@ -35,6 +35,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--songs", type=int, default=1000000)
     ap.add_argument("--every", type=int, default=100000)
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--skip-alloc", action="store_true")
     ap.add_argument("--proxy-songs", type=int, default=96000)
     ap.add_argument("--proxy-runs", type=int, default=8)
     ap.add_argument("--skip-build", action="store_true")
@@ -42,7 +44,8 @@ def main():
     from shazam_amd import _ffi, Table
     import bench_db
     ctx = _ffi.Context(0)
-    print(json.dumps({"alloc_cost": alloc_cost(ctx)}), flush=True)
+    if not a.skip_alloc:
+        print(json.dumps({"alloc_cost": alloc_cost(ctx)}), flush=True)
 
     if a.proxy_songs:
         # proxy of the per-rank post-exchange work: the rows of `runs` blocks of songs (what `runs` ranks would have
@@ -100,9 +103,22 @@ def main():
                          "phases": {k: round(v, 4) for k, v in ph.items() if v > 5e-4}})
             print(json.dumps({"finalize": recs[-1]}), flush=True)
 
+        orig_seal = Table.seal_run
+
+        def timed_seal(self):
+            t0 = time.perf_counter()
+            orig_seal(self)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            ph = self.phase_stats(reset=True)
+            print(json.dumps({"seal_run": {"seal_s": round(dt, 4), "rows": self.rows(), "segments": self.segments(),
+                                           "phases": {k: round(v, 4) for k, v in ph.items() if v > 5e-4}}}), flush=True)
+
         Table.finalize = timed_finalize
-        tbl, build, bufs = bench_db.build_table(ctx, a.songs, 30.0, 1000, 4000, 1500, finalize_every=a.every)
+        Table.seal_run = timed_seal
+        tbl, build, bufs = bench_db.build_table(ctx, a.songs, a.seconds, 1000, 4000, 1500, finalize_every=a.every)
         Table.finalize = orig
+        Table.seal_run = orig_seal
         print(json.dumps({"build": build}), flush=True)
         tbl.close()
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHZ_LIB") or os.path.join(_HERE, "libshz.so")  # SHZ_LIB: A/B builds of the same ABI
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
-PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER, MATCH_FULL_SORT = 1, 2, 4, 8, 16
+PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER, MATCH_FULL_SORT, RESERVE_GATHER = 1, 2, 4, 8, 16, 32
 NFFT, HOP, NBINS = 4096, 2048, 2049
 
 u8p, u16p, u32p, i32p, u64p, i16p, f64p = (C.POINTER(t) for t in (
@@ -25,6 +25,7 @@ SIGNATURES = {
     "shz_last_error": (C.c_char_p, [vp]),
     "shz_version": (C.c_char_p, []),
     "shz_device_info": (C.c_int32, [vp, C.c_char_p, C.c_uint64, u64p, i32p, i32p]),
+    "shz_mem_info": (C.c_int32, [vp, u64p, u64p]),
     "shz_dev_alloc": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),
     "shz_dev_free": (C.c_int32, [vp, vp]),
     "shz_copy_h2d": (C.c_int32, [vp, vp, vp, C.c_uint64]),
@@ -61,6 +62,8 @@ SIGNATURES = {
     "shz_table_insert_clips": (C.c_int32, [vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "shz_table_finalize": (C.c_int32, [vp]),
     "shz_table_set_segment_rows": (C.c_int32, [vp, C.c_uint64]),
+    "shz_table_reserve": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "shz_table_seal_run": (C.c_int32, [vp]),
     "shz_table_rows": (C.c_int32, [vp, u64p, u64p]),
     "shz_table_segments": (C.c_int32, [vp, vp]),
     "shz_table_delete_songs": (C.c_int32, [vp, vp, C.c_uint64, u64p]),
@@ -196,6 +199,12 @@ class Context:
         hbm, cus, clk = C.c_uint64(), C.c_int32(), C.c_int32()
         self.check(lib().shz_device_info(self.h, name, 256, C.byref(hbm), C.byref(cus), C.byref(clk)))
         return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cus.value, "clock_khz": clk.value}
+
+    def mem_info(self):
+        """(free, total) bytes of device memory right now."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.check(lib().shz_mem_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def alloc(self, nbytes) -> DevBuf:
         return DevBuf(self, nbytes)
@@ -456,6 +465,14 @@ class Table:
 
     def finalize(self):
         self.ctx.check(lib().shz_table_finalize(self.h))
+
+    def reserve(self, rows_hint: int, batch_rows_hint: int = 0, gather: bool = False):
+        """Announce the size of a bulk build: the table's arenas are allocated once, beside the first batches."""
+        self.ctx.check(lib().shz_table_reserve(self.h, int(rows_hint), int(batch_rows_hint), RESERVE_GATHER if gather else 0))
+
+    def seal_run(self):
+        """Staged rows -> one sorted run (not yet visible to queries); finalize() merges the runs."""
+        self.ctx.check(lib().shz_table_seal_run(self.h))
 
     def delete_songs(self, sids) -> int:
         """Remove every row of the listed song ids (ON DELETE CASCADE, mysql_database.py:57-58); returns rows removed."""

@@ -169,6 +169,21 @@ __global__ void tbl_slice_scatter_kernel(const uint32_t* __restrict__ key, const
 }
 
 // ---------------------------------------------------------------------------------------- table API
+// the bulk build (sorted runs + k-way merge, further down)
+static void reserve_wait(shz_table* t, int which);
+static int32_t seal_staged(shz_table* t, const uint64_t* block_rows, uint32_t n_blocks, bool* packed);
+static int32_t flush_runs(shz_table* t, bool final);
+static int32_t staged_minmax(shz_table* t, uint64_t lo, uint64_t n, uint32_t out[3]);
+static void reserve_cancel(shz_table* t);
+
+// columns that were not carved from the slab go back to the device
+static void free_cols(bool slab, uint32_t* key, uint32_t* sid, uint32_t* off) {
+  if (slab) return;
+  void* ps[] = {key, sid, off};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+}
+
 extern "C" int32_t shz_table_create(shz_ctx* ctx, shz_table** out) {
   if (!ctx || !out) return SHZ_E_INVALID;
   shz_table* t = new shz_table();
@@ -181,13 +196,14 @@ extern "C" int32_t shz_table_destroy(shz_table* t) {
   if (!t) return SHZ_E_INVALID;
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
-  void* ps[] = {t->key, t->sid, t->off, t->skey, t->ssid, t->soff, t->bucket};
+  reserve_cancel(t);
+  free_cols(t->act_slab, t->key, t->sid, t->off);
+  void* ps[] = {t->skey, t->ssid, t->soff, t->bucket, t->rbuf, t->slab};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   for (shz_seg& g : t->done) {
-    void* qs[] = {g.key, g.sid, g.off, g.bucket};
-    for (void* p : qs)
-      if (p) (void)hipFree(p);
+    free_cols(g.slab, g.key, g.sid, g.off);
+    if (g.bucket) (void)hipFree(g.bucket);
   }
   delete t;
   return SHZ_OK;
@@ -196,6 +212,7 @@ extern "C" int32_t shz_table_destroy(shz_table* t) {
 static int32_t stage_reserve(shz_table* t, uint64_t extra) {
   shz_ctx* ctx = t->ctx;
   const uint64_t need = t->ns + extra;
+  if (t->job && !t->skey) reserve_wait(t, 1 /* RJ_STAGE */);
   if (need <= t->scap) return SHZ_OK;
   uint64_t cap = std::max<uint64_t>(need, t->scap * 2);
   cap = std::max<uint64_t>(cap, 1024);
@@ -319,10 +336,12 @@ __global__ __launch_bounds__(256) void tbl_merge_kernel(const uint64_t* __restri
 }
 
 // merge `ns` staged rows (columns skey/ssid/soff, not freed here) into the active segment
-static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_t* ssid, const uint32_t* soff, uint64_t ns) {
+static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_t* ssid, const uint32_t* soff, uint64_t ns,
+                               uint32_t sid_lo, uint32_t sid_hi) {
   shz_ctx* ctx = t->ctx;
   const uint64_t total = t->n + ns;
   if (total >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "segment limited to < 2^32 rows (have %llu)", (unsigned long long)total);
+  if (t->n == 0) { t->act_sid_lo = 0xFFFFFFFFu; t->act_sid_hi = 0; }
   void *k0, *k1, *v0 = nullptr, *v1 = nullptr, *mx, *fl, *ps, *tot;
   ph_clock pc(t);
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &mx));
@@ -426,9 +445,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
       for (int i = 0; i < 3; ++i)
         if (uint32_t* q = fresh.take(i)) (void)hipFree(q);
       (void)hipGetLastError();
-      void* olds[] = {t->key, t->sid, t->off};
-      for (void* p : olds)
-        if (p) (void)hipFree(p);
+      free_cols(t->act_slab, t->key, t->sid, t->off);
       t->key = t->sid = t->off = nullptr;
       t->cap = 0;
       t->n = 0;
@@ -438,14 +455,13 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
                                    "the table lost rows and refuses further use", (unsigned long long)want);
       }
     } else {
-      void* olds[] = {t->key, t->sid, t->off};
-      for (void* p : olds)
-        if (p) SHZ_HIP(ctx, hipFree(p));
+      free_cols(t->act_slab, t->key, t->sid, t->off);
     }
     t->key = fresh.take(0);
     t->sid = fresh.take(1);
     t->off = fresh.take(2);
     t->cap = want;
+    t->act_slab = false;
   }
   pc.lap(PH_COL_ALLOC);
   t->n = 0;
@@ -463,6 +479,8 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   pc.lap(PH_COMPACT);
   t->n = nu;
+  t->act_sid_lo = std::min(t->act_sid_lo, sid_lo);
+  t->act_sid_hi = std::max(t->act_sid_hi, sid_hi);
   t->nbuckets = (uint64_t)(last_key >> 8) + 1;
   if (t->nbuckets + 1 > t->bcap) {
     if (t->bucket) SHZ_HIP(ctx, hipFree(t->bucket));
@@ -575,6 +593,7 @@ extern "C" int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, ui
   if (n_sids == 0) return SHZ_OK;
   if (!sids) SHZ_FAIL(ctx, SHZ_E_INVALID, "sids is NULL");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (!t->runs.empty()) SHZ_TRY(flush_runs(t, true));   // sealed runs become segments first: rows leave segments and staged rows
   uint32_t mx = 0;
   for (uint64_t i = 0; i < n_sids; ++i) mx = std::max(mx, sids[i]);
   const uint32_t nbits = mx + 1;
@@ -605,9 +624,8 @@ extern "C" int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, ui
   // frozen segments that became empty disappear
   for (size_t i = t->done.size(); i-- > 0;)
     if (t->done[i].n == 0) {
-      void* qs[] = {t->done[i].key, t->done[i].sid, t->done[i].off, t->done[i].bucket};
-      for (void* p : qs)
-        if (p) (void)hipFree(p);
+      free_cols(t->done[i].slab, t->done[i].key, t->done[i].sid, t->done[i].off);
+      if (t->done[i].bucket) (void)hipFree(t->done[i].bucket);
       t->done.erase(t->done.begin() + (long)i);
     }
   if (t->n) {
@@ -635,11 +653,16 @@ extern "C" int32_t shz_table_clear(shz_table* t) {
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (shz_seg& g : t->done) {
-    void* qs[] = {g.key, g.sid, g.off, g.bucket};
-    for (void* p : qs)
-      if (p) (void)hipFree(p);
+    free_cols(g.slab, g.key, g.sid, g.off);
+    if (g.bucket) (void)hipFree(g.bucket);
   }
   t->done.clear();
+  t->runs.clear();
+  t->run_sb = t->run_ob = 0;
+  if (t->act_slab) { t->key = t->sid = t->off = nullptr; t->cap = 0; t->act_slab = false; }   // the slab starts over: nothing is carved
+  t->slab_used = 0;
+  t->act_sid_lo = 0xFFFFFFFFu;
+  t->act_sid_hi = 0;
   t->n = 0;        // the active and staging columns keep their allocations for the rows to come
   t->nbuckets = 0;
   t->ns = 0;
@@ -649,16 +672,22 @@ extern "C" int32_t shz_table_clear(shz_table* t) {
 }
 
 // INSERT IGNORE across segments: staged rows that already sit in a frozen segment are dropped before they are merged
-static int32_t drop_staged_duplicates_of_frozen(shz_table* t) {
+// (a frozen segment whose song ids do not meet [sid_lo, sid_hi] of the staged rows cannot hold one of them: song_id is
+// part of the UNIQUE key, and ingest hands out fresh ids -- the search over every segment per finalize was what made the
+// 1M-song build's finalize 4x slower in round 2)
+static int32_t drop_staged_duplicates_of_frozen(shz_table* t, uint32_t sid_lo, uint32_t sid_hi) {
   shz_ctx* ctx = t->ctx;
   if (t->done.empty() || t->ns == 0) return SHZ_OK;
+  bool any = false;
+  for (const shz_seg& g : t->done) any |= g.n && ranges_overlap(g.sid_lo, g.sid_hi, sid_lo, sid_hi);
+  if (!any) return SHZ_OK;
   void* fl;
   ph_clock pc(t);
   struct lap_on_exit { ph_clock& c; ~lap_on_exit() { c.lap(PH_DEDUP_FROZEN); } } loe{pc};
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, t->ns * 4, &fl));
   hipLaunchKernelGGL(tbl_ones_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)fl, t->ns);
   for (const shz_seg& g : t->done) {
-    if (!g.n) continue;
+    if (!g.n || !ranges_overlap(g.sid_lo, g.sid_hi, sid_lo, sid_hi)) continue;
     shz_seg_dev gd{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets};
     hipLaunchKernelGGL(tbl_exists_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, gd, (uint32_t*)fl);
@@ -672,10 +701,13 @@ static int32_t drop_staged_duplicates_of_frozen(shz_table* t) {
 
 static void freeze_active(shz_table* t) {
   if (!t->n) return;
-  t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
+  t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab});
   t->key = t->sid = t->off = t->bucket = nullptr;
   t->n = t->nbuckets = 0;
   t->cap = t->bcap = 0;
+  t->act_slab = false;
+  t->act_sid_lo = 0xFFFFFFFFu;
+  t->act_sid_hi = 0;
 }
 
 extern "C" int32_t shz_table_finalize(shz_table* t) {
@@ -683,6 +715,25 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   shz_ctx* ctx = t->ctx;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  static const bool no_runs = [] { const char* e = getenv("SHZ_BUILD_RUNS"); return e && atoi(e) == 0; }();
+  if (t->n == 0 && (t->ns || !t->runs.empty()) && (!no_runs || !t->runs.empty())) {
+    // the bulk path: an empty active segment takes the rows as sorted runs and one k-way merge
+    bool packed = false;
+    SHZ_TRY(seal_staged(t, nullptr, 0, &packed));
+    if (packed) {
+      SHZ_TRY(flush_runs(t, true));
+      if (!t->bucket && t->n == 0 && t->done.empty()) {  // every row was a duplicate of nothing: still an empty table
+        SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
+        SHZ_HIP(ctx, hipMemsetAsync(t->bucket, 0, 8, ctx->stream));
+        t->nbuckets = 1;
+      }
+      return SHZ_OK;
+    }
+    if (!t->runs.empty()) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "song ids and offsets outgrew 32 bits while sealed runs were waiting");
+  }
+  uint32_t smm[3] = {0u, 0u, 0xFFFFFFFFu};   // largest song id / offset, smallest song id of the staged rows
+  if (t->ns) SHZ_TRY(staged_minmax(t, 0, t->ns, smm));
+  const uint32_t st_lo = smm[2], st_hi = smm[0];
   if (t->ns && t->n && t->n + t->ns > t->seg_limit) {
     // The staged rows do not fit the active segment.  Before it is frozen it is topped up with the slices (by key) of
     // the staged rows that still fit: segments then hold ~seg_limit rows instead of whatever multiple of the ingest
@@ -691,7 +742,7 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
     const uint32_t S = 64;
     const uint32_t m = (uint32_t)std::min<uint64_t>(S - 1, (t->seg_limit - t->n) * S / t->ns);
     if (m >= S / 16) {
-      SHZ_TRY(drop_staged_duplicates_of_frozen(t));
+      SHZ_TRY(drop_staged_duplicates_of_frozen(t, st_lo, st_hi));
       if (t->ns) {
         ph_clock pc(t);
         void *fa, *fb, *pa, *pb, *tot, *ak, *as, *ao, *bk, *bs, *bo;
@@ -731,13 +782,13 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
           }
           t->ns = nb;
           pc.lap(PH_TOPUP);
-          SHZ_TRY(finalize_active(t, (const uint32_t*)ak, (const uint32_t*)as, (const uint32_t*)ao, na));
+          SHZ_TRY(finalize_active(t, (const uint32_t*)ak, (const uint32_t*)as, (const uint32_t*)ao, na, st_lo, st_hi));
         }
       }
     }
     freeze_active(t);   // what is still staged starts new segment(s)
   }
-  SHZ_TRY(drop_staged_duplicates_of_frozen(t));                  // UNIQUE(song_id, offset, hash) across segments
+  SHZ_TRY(drop_staged_duplicates_of_frozen(t, st_lo, st_hi));    // UNIQUE(song_id, offset, hash) across segments
   if (t->ns == 0) {
     if (!t->bucket && t->n == 0 && t->done.empty()) {  // empty table: one empty bucket
       SHZ_HIP(ctx, hipMalloc(&t->bucket, 2 * 4));
@@ -750,13 +801,13 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   // staged rows are cut into slices BY KEY (all copies of a row land in the same slice, so duplicates
   // inside one batch are still removed), one new segment per slice
   if (t->n + t->ns <= t->seg_limit) {
-    SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns));
+    SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns, st_lo, st_hi));
   } else {   // t->n == 0 here: the active segment was frozen above
     const uint32_t nsl = (uint32_t)((t->ns + t->seg_limit - 1) / t->seg_limit) + (t->ns > t->seg_limit ? 1 : 0);
     if (t->done.size() + nsl > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
     for (uint32_t sl = 0; sl < nsl; ++sl) {
       if (nsl == 1) {
-        SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns));
+        SHZ_TRY(finalize_active(t, t->skey, t->ssid, t->soff, t->ns, st_lo, st_hi));
       } else {
         void *fl, *ps, *tot, *ck, *cs, *co;
         ph_clock pc(t);
@@ -779,7 +830,7 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
                            (const uint32_t*)fl, (const uint32_t*)ps, t->ns, (uint32_t*)ck, (uint32_t*)cs, (uint32_t*)co);
         SHZ_HIP(ctx, hipGetLastError());
         pc.lap(PH_SLICE);
-        SHZ_TRY(finalize_active(t, (const uint32_t*)ck, (const uint32_t*)cs, (const uint32_t*)co, cnt));
+        SHZ_TRY(finalize_active(t, (const uint32_t*)ck, (const uint32_t*)cs, (const uint32_t*)co, cnt, st_lo, st_hi));
       }
       if (sl + 1 < nsl) freeze_active(t);
     }
@@ -789,7 +840,7 @@ extern "C" int32_t shz_table_finalize(shz_table* t) {
   size_t mem_free = 0, mem_total = 0;
   ph_clock pcf(t);
   SHZ_HIP(ctx, hipMemGetInfo(&mem_free, &mem_total));
-  if (t->scap * 12 > mem_free / 4) {
+  if (!t->stage_reserved && t->scap * 12 > mem_free / 4) {
     void* st[] = {t->skey, t->ssid, t->soff};
     for (void* p : st)
       if (p) SHZ_HIP(ctx, hipFree(p));
@@ -817,7 +868,7 @@ extern "C" int32_t shz_table_set_segment_rows(shz_table* t, uint64_t rows) {
 extern "C" int32_t shz_table_rows(shz_table* t, uint64_t* n_rows, uint64_t* n_staged) {
   if (!t) return SHZ_E_INVALID;
   if (n_rows) *n_rows = total_rows(t);
-  if (n_staged) *n_staged = t->ns;
+  if (n_staged) *n_staged = pending_rows(t);
   return SHZ_OK;
 }
 
@@ -827,7 +878,7 @@ extern "C" int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid
   shz_ctx* ctx = t->ctx;
   const uint64_t nrows = total_rows(t);
   if (count) *count = nrows;
-  if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has %llu staged rows; call shz_table_finalize first", (unsigned long long)t->ns);
+  if (pending_rows(t)) SHZ_FAIL(ctx, SHZ_E_STATE, "table has %llu staged rows; call shz_table_finalize first", (unsigned long long)pending_rows(t));
   if (nrows > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "need %llu rows", (unsigned long long)nrows);
   if (nrows == 0) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -845,7 +896,7 @@ extern "C" int32_t shz_table_export(shz_table* t, uint32_t* key32, uint32_t* sid
 extern "C" int32_t shz_table_song_rows(shz_table* t, uint32_t sid, uint64_t* n_rows) {
   if (!t || !n_rows) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
-  if (t->ns) SHZ_FAIL(ctx, SHZ_E_STATE, "table has staged rows; call shz_table_finalize first");
+  if (pending_rows(t)) SHZ_FAIL(ctx, SHZ_E_STATE, "table has staged rows; call shz_table_finalize first");
   *n_rows = 0;
   if (total_rows(t) == 0) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -941,7 +992,7 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
   if (!t) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
   if (count) *count = 0;
-  if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (pending_rows(t) || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
   if (n_keys == 0) return SHZ_OK;
   if (!keys) SHZ_FAIL(ctx, SHZ_E_INVALID, "keys is NULL");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -969,203 +1020,901 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
   return SHZ_OK;
 }
 
-// ---------------------------------------------------------------------------------------- all-gather build
-// ---- building a table from SORTED RUNS ("every rank merges 8 sorted runs") ---------------------------------
-// Rows travel and merge in the packed form key << (sb + ob) | sid << ob | off (8 bytes a row instead of 12; its order is
-// the table's order), which needs sid and offset to fit 32 bits together -- true for every configuration of BASELINE
-// (1M songs = 20 bits, 3-minute tracks = 12 bits).
+// ---------------------------------------------------------------------------------------- bulk build: runs + k-way merge
+// The database build (fingerprint_directory's insert loop, __init__.py:378-386, at the scale of BASELINE configs 2-4):
+//   staged rows --seal--> SORTED RUNS of packed rows in the run arena --one k-way merge--> segment columns in the slab.
+// Rows travel, sort and merge in the packed form key << (sb + ob) | sid << ob | off (8 bytes a row; its numeric order is
+// the table's order), which needs song id and offset to fit 32 bits together -- true for every configuration of
+// BASELINE (1M songs = 20 bits, 3-minute tracks = 12 bits); other tables take the column path (finalize_active).
+//   * a run is sorted once, by the rank (or ingest batch) that made it, and never again;
+//   * N runs are merged in ONE pass ("every rank merges 8 sorted runs"): sampled splitters cut the value
+//     range into tiles of ~2,048 rows, a workgroup loads its tile's share of every run into LDS, ranks every element by
+//     binary searches in the other runs' shares, and writes the rows straight into the segment's three columns --
+//     8 bytes read and 12 written per row, no intermediate merged run, no pass per level of a merge tree;
+//   * after shz_table_reserve the build performs no device allocation: the slab (columns), the run arena, the staging
+//     columns and the sort scratch exist before the first batch arrives (allocated on a helper thread beside it).
 
 #define SHZ_I_GENERAL_PATH 1   // internal: the packed sorted-run path does not apply, take the column path
 
-// flag[i] = 1 where c[i] differs from its predecessor (prev = the element before c[0], if the chunk has one)
-__global__ void tbl_uniq1_chunk_kernel(const uint64_t* __restrict__ c, uint64_t n, bool has_prev, uint32_t* __restrict__ flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = ((i == 0 && !has_prev) || c[i] != c[(int64_t)i - 1]) ? 1u : 0u;
+#define KW_MAXK 16             // runs one merge takes (more: the oldest are merged into one first)
+#define KW_THREADS 256
+#define KW_TILE 2048           // nominal rows of a tile = samples per tile x sample stride
+#define KW_TMAX (3 * KW_TILE)  // a tile holds fewer than (c + 2 k) M <= 3 c M rows (c samples per tile >= k runs, stride M)
+#define KW_PER (KW_TMAX / KW_THREADS)
+
+struct kw_runs {
+  const uint64_t* p[KW_MAXK];
+  uint32_t n[KW_MAXK];
+  uint32_t soff[KW_MAXK + 1];   // first sample of every run in the sample array
+  uint32_t k;
+};
+
+// reserve job: three allocations in the order the build needs them, made by a helper thread
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+struct shz_reserve_job {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  int done = 0;                  // allocations finished so far (1: staging, 2: run arena + sort scratch, 3: slab)
+  int device = 0;
+  uint64_t stage_rows = 0, run_rows = 0, slab_bytes = 0, sort_bytes = 0;
+  uint32_t* st[3] = {nullptr, nullptr, nullptr};
+  uint64_t* rbuf = nullptr;
+  void* sortbuf[2] = {nullptr, nullptr};
+  char* slab = nullptr;
+  bool failed = false;
+};
+enum { RJ_STAGE = 1, RJ_RUNS = 2, RJ_SLAB = 3 };
+
+static void reserve_cancel(shz_table* t) {   // the table goes away (or starts over): take what the helper thread made
+  if (t->job) reserve_wait(t, RJ_SLAB);
 }
 
-// pack + sort rows [0, n) of three columns into `dst` (scratch `tmp`, both n entries)
-static int32_t pack_sort_run(shz_ctx* ctx, const uint32_t* key, const uint32_t* sid, const uint32_t* off, uint64_t n, int sb,
-                             int ob, uint64_t* dst, uint64_t* tmp) {
-  if (n == 0) return SHZ_OK;
-  if (n >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "a run is limited to < 2^32 rows (have %llu)", (unsigned long long)n);
-  hipLaunchKernelGGL(tbl_compose1_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
-                     key, sid, off, n, (uint64_t)0, sb, ob, dst);
-  SHZ_HIP(ctx, hipGetLastError());
-  int sel = 0;
-  SHZ_TRY(shz_sort_u64(ctx, dst, tmp, nullptr, nullptr, 0, n, 0, 32 + sb + ob, &sel));
-  if (sel) SHZ_HIP(ctx, hipMemcpyAsync(dst, tmp, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+static void reserve_worker(shz_reserve_job* j) {
+  (void)hipSetDevice(j->device);
+  auto step = [&](int n) { std::lock_guard<std::mutex> lk(j->mu); j->done = n; j->cv.notify_all(); };
+  bool ok = true;
+  for (auto& q : j->st) ok = ok && j->stage_rows && hipMalloc(&q, j->stage_rows * 4) == hipSuccess;
+  if (!ok) { for (auto& q : j->st) { if (q) (void)hipFree(q); q = nullptr; } (void)hipGetLastError(); }
+  step(RJ_STAGE);
+  if (j->run_rows && hipMalloc(&j->rbuf, j->run_rows * 8) != hipSuccess) { j->rbuf = nullptr; (void)hipGetLastError(); }
+  for (auto& q : j->sortbuf)
+    if (j->sort_bytes && hipMalloc(&q, j->sort_bytes) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+  step(RJ_RUNS);
+  if (j->slab_bytes && hipMalloc(&j->slab, j->slab_bytes) != hipSuccess) { j->slab = nullptr; j->failed = true; (void)hipGetLastError(); }
+  step(RJ_SLAB);
+}
+
+// block until the helper thread has made allocation `which`, and take over what it made
+static void reserve_wait(shz_table* t, int which) {
+  shz_reserve_job* j = t->job;
+  if (!j) return;
+  const double t0 = now_s();
+  {
+    std::unique_lock<std::mutex> lk(j->mu);
+    j->cv.wait(lk, [&] { return j->done >= which; });
+  }
+  shz_ctx* ctx = t->ctx;
+  if (j->st[0] && t->ns == 0 && !t->skey) {
+    t->skey = j->st[0]; t->ssid = j->st[1]; t->soff = j->st[2];
+    t->scap = j->stage_rows;
+    t->stage_reserved = true;
+    j->st[0] = j->st[1] = j->st[2] = nullptr;
+  }
+  if (which >= RJ_RUNS) {
+    if (j->rbuf && !t->rbuf) { t->rbuf = j->rbuf; t->rcap = j->run_rows; j->rbuf = nullptr; }
+    const int slots[2] = {SHZ_WS_SORT_A, SHZ_WS_SORT_B};
+    for (int i = 0; i < 2; ++i)
+      if (j->sortbuf[i]) {
+        shz_buf& b = ctx->ws[slots[i]];
+        if (b.cap < j->sort_bytes) {
+          if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); }
+          b.p = j->sortbuf[i];
+          b.cap = j->sort_bytes;
+        } else {
+          (void)hipFree(j->sortbuf[i]);
+        }
+        j->sortbuf[i] = nullptr;
+      }
+  }
+  if (which >= RJ_SLAB) {
+    if (j->slab && !t->slab) { t->slab = j->slab; t->slab_bytes = j->slab_bytes; t->slab_used = 0; j->slab = nullptr; }
+    j->th.join();
+    for (auto& q : j->st) if (q) (void)hipFree(q);
+    if (j->rbuf) (void)hipFree(j->rbuf);
+    delete j;
+    t->job = nullptr;
+  }
+  t->ph[PH_RESERVE_WAIT] += now_s() - t0;
+}
+
+extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t batch_rows_hint, uint32_t flags) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  if (t->job || t->slab) return SHZ_OK;   // one reservation per table
+  if (rows_hint == 0) return SHZ_OK;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (batch_rows_hint == 0) batch_rows_hint = rows_hint;
+  batch_rows_hint = std::min<uint64_t>(batch_rows_hint, (1ull << 32) - 4096);
+  shz_reserve_job* j = new shz_reserve_job();
+  j->device = ctx->device;
+  j->stage_rows = t->skey ? 0 : batch_rows_hint + batch_rows_hint / 16 + 1024;
+  // run arena: what is merged at once.  One GPU: a segment's worth of runs + the batch being sealed + the remainder a
+  // flush leaves; the gathered build (SHZ_RESERVE_GATHER): this rank's run beside every rank's.
+  const uint64_t seg = std::min<uint64_t>(rows_hint, t->seg_limit);
+  j->run_rows = (flags & SHZ_RESERVE_GATHER) ? rows_hint + batch_rows_hint + batch_rows_hint / 8 + 65536
+                                             : seg + 2 * (batch_rows_hint + batch_rows_hint / 16) + 65536;
+  j->sort_bytes = (batch_rows_hint + batch_rows_hint / 16 + 65536) * 8;
+  // columns: 12 bytes a row, 256-byte aligned per column, + 2 % for duplicates-free estimates that run a little over
+  j->slab_bytes = ((rows_hint + rows_hint / 50 + 65536) * 12 + 4095) & ~4095ull;
+  size_t mem_free = 0, mem_total = 0;
+  SHZ_HIP(ctx, hipMemGetInfo(&mem_free, &mem_total));
+  const uint64_t want = j->slab_bytes + j->run_rows * 8 + j->stage_rows * 12 + 2 * j->sort_bytes;
+  if (want > (uint64_t)mem_free - ((uint64_t)mem_free >> 4)) {
+    delete j;
+    SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_table_reserve: %llu rows need %.1f GB of device memory, %.1f GB are free",
+             (unsigned long long)rows_hint, want / 1e9, mem_free / 1e9);
+  }
+  t->job = j;
+  j->th = std::thread(reserve_worker, j);
   return SHZ_OK;
 }
 
-// merge the sorted runs run_off[r] .. run_off[r+1] of `a` pairwise, ping-ponging with `b`, until one run is left;
-// *out = the buffer that holds it
-static int32_t merge_runs(shz_ctx* ctx, uint64_t* a, uint64_t* b, std::vector<uint64_t> run_off, uint64_t** out) {
-  while (run_off.size() > 2) {
-    std::vector<uint64_t> next{0};
-    const size_t nr = run_off.size() - 1;
-    for (size_t r = 0; r < nr; r += 2) {
-      const uint64_t o0 = run_off[r], o1 = run_off[r + 1], o2 = r + 2 <= nr ? run_off[r + 2] : o1;
-      if (r + 1 == nr) {  // odd run out: carried over
-        if (o1 > o0) SHZ_HIP(ctx, hipMemcpyAsync(b + o0, a + o0, (o1 - o0) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        next.push_back(o1);
-      } else {
-        const uint64_t tot = o2 - o0;
-        if (tot) {
-          if ((tot + MERGE_TILE - 1) / MERGE_TILE >= (1ull << 31)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "merge of %llu rows", (unsigned long long)tot);
-          hipLaunchKernelGGL(tbl_merge_kernel, dim3((unsigned)((tot + MERGE_TILE - 1) / MERGE_TILE)), dim3(256), 0, ctx->stream,
-                             (const uint64_t*)(a + o0), o1 - o0, (const uint64_t*)(a + o1), o2 - o1, b + o0);
-          SHZ_HIP(ctx, hipGetLastError());
+// three columns of `rows` rows: from the slab while it lasts, else three allocations
+static int32_t carve_cols(shz_table* t, uint64_t rows, uint32_t** k, uint32_t** s, uint32_t** o, bool* from_slab) {
+  shz_ctx* ctx = t->ctx;
+  reserve_wait(t, RJ_SLAB);
+  const uint64_t col = (std::max<uint64_t>(rows, 1) * 4 + 255) & ~255ull;
+  if (t->slab && t->slab_used + 3 * col <= t->slab_bytes) {
+    char* b = t->slab + t->slab_used;
+    *k = (uint32_t*)b; *s = (uint32_t*)(b + col); *o = (uint32_t*)(b + 2 * col);
+    t->slab_used += 3 * col;
+    *from_slab = true;
+    return SHZ_OK;
+  }
+  dev_cols c;
+  if (!c.alloc(rows)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)rows);
+  *k = c.take(0); *s = c.take(1); *o = c.take(2);
+  *from_slab = false;
+  return SHZ_OK;
+}
+
+// the run arena holds at least `rows` rows (contents kept)
+static int32_t rbuf_reserve(shz_table* t, uint64_t rows) {
+  shz_ctx* ctx = t->ctx;
+  reserve_wait(t, RJ_RUNS);
+  if (rows <= t->rcap) return SHZ_OK;
+  uint64_t used = 0;
+  for (const shz_run& r : t->runs) used = std::max(used, r.off + r.n);
+  const uint64_t cap = std::max<uint64_t>(rows + rows / 8 + 1024, 1024);
+  uint64_t* nb = nullptr;
+  if (hipMalloc(&nb, cap * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "run arena: hipMalloc(%llu) failed", (unsigned long long)(cap * 8));
+  if (used) SHZ_HIP(ctx, hipMemcpyAsync(nb, t->rbuf, used * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (t->rbuf) SHZ_HIP(ctx, hipFree(t->rbuf));
+  t->rbuf = nb;
+  t->rcap = cap;
+  return SHZ_OK;
+}
+
+// ---- kernels of the seal ----
+// largest song id / offset and smallest song id of n rows: out[0] max sid, out[1] max off, out[2] min sid (preset to ~0)
+__global__ void tbl_minmax_kernel(const uint32_t* __restrict__ sid, const uint32_t* __restrict__ off, uint64_t n,
+                                  uint32_t* __restrict__ out) {
+  uint32_t s = 0, o = 0, m = 0xFFFFFFFFu;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t x = sid[i];
+    s = max(s, x);
+    m = min(m, x);
+    o = max(o, off[i]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s = max(s, (uint32_t)__shfl_xor((int)s, d, 64));
+    o = max(o, (uint32_t)__shfl_xor((int)o, d, 64));
+    m = min(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], s);
+    atomicMax(&out[1], o);
+    atomicMin(&out[2], m);
+  }
+}
+
+// pack rows and note whether they already come ordered by (song id, offset) -- the order ingest produces (clips in id
+// order, a clip's hashes in time order, __init__.py:194-210): a stable sort on the key bits alone then yields the full
+// order, four radix passes instead of eight.  *unordered is set when some row sorts before its predecessor.
+__global__ void run_pack_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ sid,
+                                const uint32_t* __restrict__ off, uint64_t n, int sb, int ob, uint64_t* __restrict__ out,
+                                uint32_t* __restrict__ unordered) {
+  bool bad = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t lo = ((uint64_t)sid[i] << ob) | off[i];
+    out[i] = ((uint64_t)key[i] << (sb + ob)) | lo;
+    if (i) bad |= lo < (((uint64_t)sid[i - 1] << ob) | off[i - 1]);
+  }
+  if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(unordered, 1u);
+}
+
+// rows of a sorted run that equal their predecessor
+__global__ void run_dups_kernel(const uint64_t* __restrict__ c, uint64_t n, unsigned long long* __restrict__ out) {
+  uint32_t d = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    d += (i && c[i] == c[i - 1]) ? 1u : 0u;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) d += (uint32_t)__shfl_xor((int)d, s, 64);
+  if ((threadIdx.x & 63) == 0 && d) atomicAdd(out, (unsigned long long)d);
+}
+__global__ void run_compact_kernel(const uint64_t* __restrict__ c, const uint32_t* __restrict__ flag,
+                                   const uint32_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) out[pos[i]] = c[i];
+}
+// packed rows from one layout to another (both monotone in (key, sid, off): a sorted run stays sorted)
+__global__ void run_repack_kernel(uint64_t* __restrict__ c, uint64_t n, int sb0, int ob0, int sb1, int ob1) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = c[i];
+    const uint64_t key = v >> (sb0 + ob0), sid = (v >> ob0) & ((1ull << sb0) - 1), off = v & ((1ull << ob0) - 1);
+    c[i] = (key << (sb1 + ob1)) | (sid << ob1) | off;
+  }
+}
+
+// ---- kernels of the k-way merge ----
+__global__ void kw_sample_kernel(kw_runs R, uint32_t M, uint64_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R.soff[R.k]) return;
+  uint32_t r = 0;
+  while (j >= R.soff[r + 1]) ++r;
+  out[j] = R.p[r][(uint64_t)(j - R.soff[r]) * M];
+}
+
+// bounds[t * k + r] = first element of run r that belongs to tile t or a later one: tile t takes the values
+// [smp[t * c], smp[(t + 1) * c)), the first tile everything below, the last everything above
+__global__ void kw_bounds_kernel(kw_runs R, const uint64_t* __restrict__ smp, uint32_t c, uint32_t ntiles,
+                                 uint32_t* __restrict__ bounds) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = R.k;
+  if (e >= ((uint64_t)ntiles + 1) * k) return;
+  const uint32_t t = (uint32_t)(e / k), r = (uint32_t)(e - (uint64_t)t * k);
+  uint32_t lo = 0, hi = R.n[r];
+  if (t == 0) hi = 0;
+  else if (t == ntiles) lo = hi;
+  else {
+    const uint64_t v = smp[(uint64_t)t * c];
+    const uint64_t* __restrict__ p = R.p[r];
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (p[mid] < v) lo = mid + 1; else hi = mid;
+    }
+  }
+  bounds[e] = lo;
+}
+
+__global__ void kw_tile_rows_kernel(const uint32_t* __restrict__ bounds, uint32_t k, uint32_t ntiles, uint64_t* __restrict__ rows) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  uint64_t s = 0;
+  if (t < ntiles)
+    for (uint32_t r = 0; r < k; ++r) s += bounds[(uint64_t)(t + 1) * k + r] - bounds[(uint64_t)t * k + r];
+  rows[t] = s;   // rows[ntiles] = 0: the exclusive scan ends in the total
+}
+
+// output pieces of at most L rows, taken greedily in whole tiles (a tile alone always counts): tile[j] = first tile of
+// piece j, row[j] = its first output row; the last entry is (ntiles, total); n = number of entries (pieces + 1)
+struct kw_cutlist {
+  uint32_t n, pad;
+  uint32_t tile[SHZ_MAX_SEGS + 4];
+  uint64_t row[SHZ_MAX_SEGS + 4];
+};
+__global__ void kw_cuts_kernel(const uint64_t* __restrict__ base, uint32_t ntiles, uint64_t L, kw_cutlist* __restrict__ out) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t pos = 0, n = 0;
+  out->tile[n] = 0; out->row[n] = 0; ++n;
+  while (pos < ntiles && n < SHZ_MAX_SEGS + 3) {
+    uint32_t lo = pos + 1, hi = ntiles;   // largest e in [pos + 1, ntiles] with base[e] - base[pos] <= L
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo + 1) >> 1);
+      if (base[mid] - base[pos] <= L) lo = mid; else hi = mid - 1;
+    }
+    pos = lo;
+    out->tile[n] = pos; out->row[n] = base[pos]; ++n;
+  }
+  out->n = n;
+}
+
+// One tile of the merge.  MODE 0: rows -> columns; 1: count the tile's distinct rows; 2: rows -> columns, duplicates
+// dropped; 3: rows -> packed; 4: packed, duplicates dropped.  base[t] = output row of tile t (of the distinct rows in
+// the modes that drop duplicates); this launch writes relative to row out0.
+template <int MODE>
+__global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const uint32_t* __restrict__ bounds, uint32_t tile0,
+                                                             const uint64_t* __restrict__ base, uint64_t out0, int sb, int ob,
+                                                             uint32_t* __restrict__ okey, uint32_t* __restrict__ osid,
+                                                             uint32_t* __restrict__ ooff, uint64_t* __restrict__ opacked,
+                                                             uint64_t* __restrict__ uniq) {
+  __shared__ uint64_t buf[KW_TMAX];
+  __shared__ uint32_t s_lo[KW_MAXK], s_off[KW_MAXK + 1], s_w[KW_THREADS / 64 + 1];
+  const uint32_t t = tile0 + blockIdx.x, k = R.k, tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    uint32_t lo = 0, cnt = 0;
+    if (tid < k) { lo = bounds[(uint64_t)t * k + tid]; cnt = bounds[(uint64_t)(t + 1) * k + tid] - lo; }
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < KW_MAXK; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+      if ((int)lane >= d) inc += o;
+    }
+    if (tid < k) { s_lo[tid] = lo; s_off[tid + 1] = inc; }
+    if (tid == 0) s_off[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t total = min(s_off[k], (uint32_t)KW_TMAX);   // (the bound holds by construction; the clamp keeps a wrong plan from writing past buf)
+  for (uint32_t r = 0; r < k; ++r) {
+    const uint64_t* __restrict__ p = R.p[r] + s_lo[r];
+    const uint32_t o = s_off[r], c = min(s_off[r + 1], total) - min(o, total);
+    for (uint32_t i = tid; i < c; i += KW_THREADS) buf[o + i] = p[i];
+  }
+  __syncthreads();
+  // log2 k rounds of pairwise merges inside LDS (merge path): in round `stride` the neighbouring regions
+  // [s_off[q], s_off[q + stride]) and [s_off[q + stride], s_off[q + 2 stride]) -- each sorted -- become one.  A thread
+  // produces `per` consecutive outputs: one binary search along its diagonal, then a serial merge of the two heads;
+  // ties take the left (lower) run first.  Outputs wait in registers until every thread has read its inputs.
+  const uint32_t per = (total + KW_THREADS - 1) / KW_THREADS;          // uniform, <= KW_PER
+  const uint32_t g0 = min(tid * per, total), g1 = min(g0 + per, total);
+  for (uint32_t stride = 1; stride < k; stride <<= 1) {
+    uint64_t out[KW_PER];
+    uint32_t g = g0;
+    while (g < g1) {                                                    // one piece per region the thread's outputs touch (1, rarely 2)
+      uint32_t q = 0;
+      while (q + 2 * stride < k && s_off[min(k, q + 2 * stride)] <= g) q += 2 * stride;
+      const uint32_t a0 = min(s_off[q], total), mid = min(s_off[min(k, q + stride)], total), e = min(s_off[min(k, q + 2 * stride)], total);
+      const uint32_t na = mid - a0, nb = e - mid, d = g - a0, cnt = min(g1, e) - g, c0 = g - g0;
+      uint32_t lo = d > nb ? d - nb : 0, hi = min(d, na);
+      while (lo < hi) {                                                 // elements of A among the first d outputs
+        const uint32_t m = (lo + hi) >> 1;
+        if (buf[a0 + m] <= buf[mid + (d - 1 - m)]) lo = m + 1; else hi = m;
+      }
+      uint32_t i = lo, j = d - lo;
+      uint64_t ca = i < na ? buf[a0 + i] : 0, cb = j < nb ? buf[mid + j] : 0;
+#pragma unroll
+      for (int c = 0; c < KW_PER; ++c) {
+        if ((uint32_t)c < per && (uint32_t)c >= c0 && (uint32_t)c < c0 + cnt) {
+          const bool take_a = j >= nb || (i < na && ca <= cb);
+          out[c] = take_a ? ca : cb;
+          if (take_a) { ++i; ca = i < na ? buf[a0 + i] : 0; } else { ++j; cb = j < nb ? buf[mid + j] : 0; }
         }
-        next.push_back(o2);
+      }
+      g += cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KW_PER; ++c)
+      if ((uint32_t)c < per && g0 + c < g1) buf[g0 + c] = out[c];
+    __syncthreads();
+  }
+  // the tile is sorted in buf[0, total)
+  const int shift = sb + ob;
+  const uint64_t smask = (1ull << sb) - 1, omask = (1ull << ob) - 1;
+  if (MODE == 0 || MODE == 3) {
+    const uint64_t row0 = base[t] - out0;
+    for (uint32_t i = tid; i < total; i += KW_THREADS) {
+      const uint64_t v = buf[i];
+      if (MODE == 0) {
+        okey[row0 + i] = (uint32_t)(v >> shift);
+        osid[row0 + i] = (uint32_t)((v >> ob) & smask);
+        ooff[row0 + i] = (uint32_t)(v & omask);
+      } else {
+        opacked[row0 + i] = v;
       }
     }
-    std::swap(a, b);
-    run_off.swap(next);
+    return;
   }
-  *out = a;
+  // duplicates (equal neighbours; all copies of a value sit in one tile) are dropped: position = number of kept rows before
+  uint32_t run = 0;   // kept rows of the rounds before this one (uniform)
+  const uint64_t row0 = MODE == 1 ? 0 : base[t] - out0;
+  for (uint32_t i0 = 0; i0 < total; i0 += KW_THREADS) {
+    const uint32_t i = i0 + tid;
+    const bool keep = i < total && (i == 0 || buf[i] != buf[i - 1]);
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) s_w[tid >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < KW_THREADS / 64; ++w) {
+      const uint32_t c = s_w[w];
+      if (w < (int)(tid >> 6)) before += c;
+      all += c;
+    }
+    if (MODE != 1 && keep) {
+      const uint64_t v = buf[i];
+      const uint64_t o = row0 + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      if (MODE == 2) {
+        okey[o] = (uint32_t)(v >> shift);
+        osid[o] = (uint32_t)((v >> ob) & smask);
+        ooff[o] = (uint32_t)(v & omask);
+      } else {
+        opacked[o] = v;
+      }
+    }
+    run += all;
+    __syncthreads();
+  }
+  if (MODE == 1 && tid == 0) uniq[t] = run;
+}
+
+// ---- host side of the bulk build ----
+static uint64_t runs_end(const shz_table* t) {
+  uint64_t e = 0;
+  for (const shz_run& r : t->runs) e = std::max(e, r.off + r.n);
+  return e;
+}
+static uint64_t runs_rows(const shz_table* t) {
+  uint64_t n = 0;
+  for (const shz_run& r : t->runs) n += r.n;
+  return n;
+}
+
+// the layout every run of the table is packed in: fixed by the first run (all spare bits to the song id, which grows
+// with ingest), widened -- existing runs repacked in place -- when a later batch brings longer tracks.  false: ids and
+// offsets do not fit 32 bits together.
+static int32_t run_layout(shz_table* t, uint32_t max_sid, uint32_t max_off, bool* ok) {
+  shz_ctx* ctx = t->ctx;
+  const int need_sb = bits_for(max_sid), need_ob = bits_for(max_off);
+  *ok = need_sb + need_ob <= 32;
+  if (!*ok) return SHZ_OK;
+  if (t->run_ob && need_sb <= t->run_sb && need_ob <= t->run_ob) return SHZ_OK;
+  int ob = need_ob, sb = 32 - need_ob;
+  if (t->run_ob && !t->runs.empty()) {
+    // what the existing runs hold must still fit: their layout's fields are upper bounds
+    ob = std::max(need_ob, std::min(t->run_ob, 32 - need_sb));
+    sb = 32 - ob;
+    for (const shz_run& r : t->runs)
+      if (r.n)
+        hipLaunchKernelGGL(run_repack_kernel, dim3((unsigned)std::min<uint64_t>((r.n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                           t->rbuf + r.off, r.n, t->run_sb, t->run_ob, sb, ob);
+    SHZ_HIP(ctx, hipGetLastError());
+  }
+  t->run_sb = sb;
+  t->run_ob = ob;
   return SHZ_OK;
 }
 
-// an EMPTY table takes one sorted packed run of `total` rows: duplicates dropped, cut into segments of <= seg_limit rows
-static int32_t segments_from_sorted(shz_table* t, const uint64_t* g, uint64_t total, int sb, int ob) {
+// n rows of three columns -> one sorted run without duplicates at the end of the run arena
+static int32_t seal_rows(shz_table* t, const uint32_t* key, const uint32_t* sid, const uint32_t* off, uint64_t n, uint32_t sid_lo,
+                         uint32_t sid_hi) {
   shz_ctx* ctx = t->ctx;
-  const uint64_t L = std::min<uint64_t>(t->seg_limit, (1ull << 32) - 4096);
-  if ((total + L - 1) / L > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
-  for (uint64_t o = 0; o < total; o += L) {
-    const uint64_t n = std::min(L, total - o);
-    void *fl, *ps, *tot;
+  if (n == 0) return SHZ_OK;
+  if (n >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "a run is limited to < 2^32 rows (have %llu)", (unsigned long long)n);
+  ph_clock pc(t);
+  const uint64_t tail = (runs_end(t) + 31) & ~31ull;   // runs start 256-byte aligned (the sort loads 16 bytes per lane)
+  SHZ_TRY(rbuf_reserve(t, tail + n));
+  pc.lap(PH_RESERVE_WAIT);
+  uint64_t* dst = t->rbuf + tail;
+  void *flag, *tmp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &flag));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &tmp));
+  SHZ_HIP(ctx, hipMemsetAsync(flag, 0, 64, ctx->stream));
+  const int sb = t->run_sb, ob = t->run_ob;
+  hipLaunchKernelGGL(run_pack_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, ctx->stream, key, sid,
+                     off, n, sb, ob, dst, (uint32_t*)flag);
+  SHZ_HIP(ctx, hipGetLastError());
+  uint32_t unordered = 1;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &unordered, flag, 4, hipMemcpyDeviceToHost));
+  pc.lap(PH_RUN_PACK);
+  // rows that arrive ordered by (song id, offset) need a stable sort on the key bits only
+  int sel = 0;
+  SHZ_TRY(shz_sort_u64(ctx, dst, (uint64_t*)tmp, nullptr, nullptr, 0, n, unordered ? 0 : sb + ob, 32 + sb + ob, &sel));
+  if (sel) SHZ_HIP(ctx, hipMemcpyAsync(dst, tmp, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  pc.lap(PH_RUN_SORT);
+  // duplicates inside the run (INSERT IGNORE): counted first, compacted only if there are any
+  unsigned long long* d_dups = (unsigned long long*)flag + 1;
+  hipLaunchKernelGGL(run_dups_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
+                     (const uint64_t*)dst, n, d_dups);
+  SHZ_HIP(ctx, hipGetLastError());
+  unsigned long long dups = 0;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &dups, d_dups, 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t kept = n;
+  if (dups) {
+    void *fl, *ps;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, n * 4, &fl));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, n * 4, &ps));
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, 64, &tot));
-    hipLaunchKernelGGL(tbl_uniq1_chunk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g + o, n, o > 0,
-                       (uint32_t*)fl);
+    hipLaunchKernelGGL(tbl_uniq1_flag_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, (const uint64_t*)dst, n, (uint32_t*)fl);
+    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, n, nullptr));
+    hipLaunchKernelGGL(run_compact_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, (const uint64_t*)dst, (const uint32_t*)fl,
+                       (const uint32_t*)ps, n, (uint64_t*)tmp);
     SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)fl, (uint32_t*)ps, n, (uint64_t*)tot));
-    uint64_t nu = 0;
-    SHZ_HIP(ctx, shz_memcpy(ctx, &nu, tot, 8, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (nu == 0) continue;
-    if (t->n) freeze_active(t);   // the previous chunk's segment
-    dev_cols cols;
-    if (!cols.alloc(nu)) SHZ_FAIL(ctx, SHZ_E_NOMEM, "table: hipMalloc of %llu rows failed", (unsigned long long)nu);
-    t->key = cols.take(0); t->sid = cols.take(1); t->off = cols.take(2);
-    t->cap = nu;
-    hipLaunchKernelGGL(tbl_compact1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g + o,
-                       (const uint32_t*)fl, (const uint32_t*)ps, n, sb, ob, t->key, t->sid, t->off);
+    kept = n - dups;
+    SHZ_HIP(ctx, hipMemcpyAsync(dst, tmp, kept * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  pc.lap(PH_RUN_UNIQ);
+  t->runs.push_back(shz_run{tail, kept, sid_lo, sid_hi});
+  return SHZ_OK;
+}
+
+
+// can two of the runs hold the same row?  Only if their song-id ranges meet.
+static bool runs_may_share_rows(const std::vector<shz_run>& runs) {
+  for (size_t i = 0; i < runs.size(); ++i)
+    for (size_t j = i + 1; j < runs.size(); ++j)
+      if (runs[i].n && runs[j].n && ranges_overlap(runs[i].sid_lo, runs[i].sid_hi, runs[j].sid_lo, runs[j].sid_hi)) return true;
+  return false;
+}
+
+
+// The k-way merge of `runs` (pointers into device memory, each sorted and duplicate-free).  Output pieces of at most
+// `piece_rows` rows: the first `n_seg_pieces` of them (all if 0xFFFFFFFF) become table segments -- the last one the
+// active segment when `last_active` --, what is left is written packed to `rest` (capacity rest_cap rows) and its
+// row count to *rest_rows.  dedup: rows may repeat across runs.
+static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr, const std::vector<shz_run>& runs, bool dedup,
+                          uint64_t piece_rows, uint32_t n_seg_pieces, bool last_active, uint64_t* rest, uint64_t rest_cap,
+                          uint64_t* rest_rows) {
+  shz_ctx* ctx = t->ctx;
+  if (rest_rows) *rest_rows = 0;
+  kw_runs R;
+  memset(&R, 0, sizeof(R));
+  uint64_t total = 0;
+  uint32_t k = 0, sid_lo = 0xFFFFFFFFu, sid_hi = 0;
+  for (size_t i = 0; i < runs.size(); ++i) {
+    if (!runs[i].n) continue;
+    if (k == KW_MAXK) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "k-way merge of more than %d runs", KW_MAXK);
+    R.p[k] = ptr[i];
+    R.n[k] = (uint32_t)runs[i].n;
+    total += runs[i].n;
+    sid_lo = std::min(sid_lo, runs[i].sid_lo);
+    sid_hi = std::max(sid_hi, runs[i].sid_hi);
+    ++k;
+  }
+  if (k == 0) return SHZ_OK;
+  R.k = k;
+  ph_clock pc(t);
+  // plan: every M-th element of every run is a sample; every c-th of the sorted samples starts a tile
+  uint32_t kp2 = 1;
+  while (kp2 < k) kp2 <<= 1;
+  const uint32_t nominal = (uint32_t)std::min<uint64_t>(KW_TILE, std::max<uint64_t>(kp2, piece_rows / 8));
+  const uint32_t M = std::max<uint32_t>(1, nominal / kp2), c = kp2;
+  uint64_t S = 0;
+  for (uint32_t r = 0; r < k; ++r) { R.soff[r] = (uint32_t)S; S += (R.n[r] + M - 1) / M; }
+  if (S >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "k-way merge: %llu samples", (unsigned long long)S);
+  R.soff[k] = (uint32_t)S;
+  const uint32_t ntiles = (uint32_t)((S + c - 1) / c);
+  void *smp0, *smp1, *bnd, *rows, *base, *cutp;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, S * 8, &smp0));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, S * 8, &smp1));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, ((uint64_t)ntiles + 1) * k * 4, &bnd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, ((uint64_t)ntiles + 1) * 8, &rows));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, ((uint64_t)ntiles + 1) * 8, &base));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, sizeof(kw_cutlist), &cutp));
+  hipLaunchKernelGGL(kw_sample_kernel, dim3(nblk(S)), dim3(256), 0, ctx->stream, R, M, (uint64_t*)smp0);
+  SHZ_HIP(ctx, hipGetLastError());
+  int sel = 0;
+  if (k > 1) SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)smp0, (uint64_t*)smp1, nullptr, nullptr, 0, S, 0, 32 + t->run_sb + t->run_ob, &sel));
+  const uint64_t* smp = sel ? (const uint64_t*)smp1 : (const uint64_t*)smp0;
+  hipLaunchKernelGGL(kw_bounds_kernel, dim3(nblk(((uint64_t)ntiles + 1) * k)), dim3(256), 0, ctx->stream, R, smp, c, ntiles,
+                     (uint32_t*)bnd);
+  const int sb = t->run_sb, ob = t->run_ob;
+  if (!dedup) {
+    hipLaunchKernelGGL(kw_tile_rows_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint32_t*)bnd, k, ntiles,
+                       (uint64_t*)rows);
+  } else {   // a first pass over the tiles counts their distinct rows
+    SHZ_HIP(ctx, hipMemsetAsync((uint64_t*)rows + ntiles, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(kw_tile_kernel<1>, dim3(ntiles), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, 0u,
+                       (const uint64_t*)nullptr, (uint64_t)0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (uint64_t*)nullptr, (uint64_t*)rows);
+  }
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)rows, (uint64_t*)base, (uint64_t)ntiles + 1, nullptr));
+  hipLaunchKernelGGL(kw_cuts_kernel, dim3(1), dim3(1), 0, ctx->stream, (const uint64_t*)base, ntiles, piece_rows, (kw_cutlist*)cutp);
+  SHZ_HIP(ctx, hipGetLastError());
+  kw_cutlist hc;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &hc, cutp, sizeof(hc), hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t n_cuts = hc.n;
+  const uint32_t* cuts = hc.tile;
+  const uint64_t* cut_row = hc.row;
+  if (n_cuts < 2 || cuts[n_cuts - 1] != ntiles) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
+  pc.lap(PH_KW_PLAN);
+  const uint32_t n_pieces = n_cuts - 1;
+  const uint32_t n_seg = std::min(n_seg_pieces, n_pieces);
+  if (t->done.size() + n_seg > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
+  for (uint32_t i = 0; i < n_seg; ++i) {
+    const uint64_t r0 = cut_row[i], nrows = cut_row[i + 1] - r0;
+    const uint32_t t0 = cuts[i], nt = cuts[i + 1] - t0;
+    if (nrows == 0) continue;
+    if (t->n) freeze_active(t);
+    uint32_t *ck, *cs, *co;
+    bool from_slab = false;
+    SHZ_TRY(carve_cols(t, nrows, &ck, &cs, &co, &from_slab));
+    pc.lap(PH_COL_ALLOC);
+    if (dedup)
+      hipLaunchKernelGGL(kw_tile_kernel<2>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
+                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    else
+      hipLaunchKernelGGL(kw_tile_kernel<0>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
+                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr);
     SHZ_HIP(ctx, hipGetLastError());
-    t->n = nu;
+    // the new segment is the active one until the next piece (or the caller) freezes it
+    if (t->key && !t->act_slab) { void* olds[] = {t->key, t->sid, t->off}; for (void* p : olds) (void)hipFree(p); }
+    t->key = ck; t->sid = cs; t->off = co;
+    t->n = nrows;
+    t->cap = nrows;
+    t->act_slab = from_slab;
+    t->act_sid_lo = sid_lo;
+    t->act_sid_hi = sid_hi;
+    pc.lap(PH_KW_MERGE);
     SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap));
+    pc.lap(PH_BUCKET);
+  }
+  if (t->n && !(last_active && n_seg == n_pieces)) freeze_active(t);
+  if (n_seg < n_pieces) {   // the rest, as one packed run
+    const uint64_t r0 = cut_row[n_seg], nrows = cut_row[n_pieces] - r0;
+    const uint32_t t0 = cuts[n_seg], nt = ntiles - t0;
+    if (nrows > rest_cap || !rest) SHZ_FAIL(ctx, SHZ_E_STATE, "k-way merge: %llu rows left over, room for %llu", (unsigned long long)nrows, (unsigned long long)rest_cap);
+    if (nrows) {
+      if (dedup)
+        hipLaunchKernelGGL(kw_tile_kernel<4>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
+                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr);
+      else
+        hipLaunchKernelGGL(kw_tile_kernel<3>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
+                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr);
+      SHZ_HIP(ctx, hipGetLastError());
+    }
+    if (rest_rows) *rest_rows = nrows;
+    pc.lap(PH_KW_MERGE);
+  }
+  return SHZ_OK;
+}
+
+// Runs of the arena -> table.  final: every row becomes a segment row (the last piece stays the active segment).
+// Otherwise only FULL segments are cut (seg_limit rows each) and what is left goes back to the arena as one run.
+static int32_t flush_runs(shz_table* t, bool final) {
+  shz_ctx* ctx = t->ctx;
+  uint64_t total = runs_rows(t);
+  if (total == 0) { t->runs.clear(); return SHZ_OK; }
+  std::vector<const uint64_t*> ptr;
+  for (const shz_run& r : t->runs) ptr.push_back(t->rbuf + r.off);
+  const bool dedup = runs_may_share_rows(t->runs);
+  uint32_t sid_lo = 0xFFFFFFFFu, sid_hi = 0;
+  for (const shz_run& r : t->runs)
+    if (r.n) { sid_lo = std::min(sid_lo, r.sid_lo); sid_hi = std::max(sid_hi, r.sid_hi); }
+  const uint64_t L = std::min<uint64_t>(t->seg_limit, (1ull << 32) - 4096);
+  if (final) {
+    SHZ_TRY(kway_merge(t, ptr, t->runs, dedup, L, 0xFFFFFFFFu, true, nullptr, 0, nullptr));
+    t->runs.clear();
+    return SHZ_OK;
+  }
+  const uint32_t full = (uint32_t)(total / L);   // (duplicates across runs can only make the pieces fewer)
+  if (full == 0) return SHZ_OK;
+  // the leftover is written to scratch and moved to the front of the arena
+  const uint64_t rest_cap = total - (uint64_t)full * L + (uint64_t)KW_TMAX * (full + 1);
+  void* rest;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, rest_cap * 8, &rest));
+  uint64_t rest_rows = 0;
+  SHZ_TRY(kway_merge(t, ptr, t->runs, dedup, L, full, false, (uint64_t*)rest, rest_cap, &rest_rows));
+  t->runs.clear();
+  if (rest_rows) {
+    SHZ_TRY(rbuf_reserve(t, rest_rows));
+    SHZ_HIP(ctx, hipMemcpyAsync(t->rbuf, rest, rest_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->runs.push_back(shz_run{0, rest_rows, sid_lo, sid_hi});
+  }
+  return SHZ_OK;
+}
+
+// merge all runs of the arena into ONE run (more runs than a merge takes, or a rank about to send its rows)
+static int32_t collapse_runs(shz_table* t) {
+  shz_ctx* ctx = t->ctx;
+  if (t->runs.size() <= 1) return SHZ_OK;
+  const uint64_t total = runs_rows(t);
+  uint32_t sid_lo = 0xFFFFFFFFu, sid_hi = 0;
+  for (const shz_run& r : t->runs)
+    if (r.n) { sid_lo = std::min(sid_lo, r.sid_lo); sid_hi = std::max(sid_hi, r.sid_hi); }
+  if (total >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "a run is limited to < 2^32 rows (have %llu)", (unsigned long long)total);
+  std::vector<const uint64_t*> ptr;
+  for (const shz_run& r : t->runs) ptr.push_back(t->rbuf + r.off);
+  void* rest;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, std::max<uint64_t>(total, 1) * 8, &rest));
+  uint64_t rest_rows = 0;
+  SHZ_TRY(kway_merge(t, ptr, t->runs, runs_may_share_rows(t->runs), (1ull << 32) - 4096, 0, false, (uint64_t*)rest, total, &rest_rows));
+  t->runs.clear();
+  if (rest_rows) {
+    SHZ_HIP(ctx, hipMemcpyAsync(t->rbuf, rest, rest_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->runs.push_back(shz_run{0, rest_rows, sid_lo, sid_hi});
   }
   return SHZ_OK;
 }
 
 
-// staged rows = n_runs consecutive blocks of run_rows[r] rows: sort every block, merge the runs, build the segments.
-// With `c`, the blocks are the ranks' staged rows and travel between the sort and the merge.
+// maxima / minimum song id of the staged rows [lo, lo + n)
+static int32_t staged_minmax(shz_table* t, uint64_t lo, uint64_t n, uint32_t out[3]) {
+  shz_ctx* ctx = t->ctx;
+  void* mx;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64, &mx));
+  const uint32_t init[3] = {0u, 0u, 0xFFFFFFFFu};
+  SHZ_HIP(ctx, shz_memcpy(ctx, mx, init, 12, hipMemcpyHostToDevice));
+  if (n)
+    hipLaunchKernelGGL(tbl_minmax_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)t->ssid + lo, (const uint32_t*)t->soff + lo, n, (uint32_t*)mx);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, shz_memcpy(ctx, out, mx, 12, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+// The staged rows become one sorted run (blocks: several, one per block of block_rows[] rows).  *packed = false when
+// the packed form does not apply (ids + offsets wider than 32 bits, or the active segment holds rows): nothing was done,
+// the caller takes the column path.
+static int32_t seal_staged(shz_table* t, const uint64_t* block_rows, uint32_t n_blocks, bool* packed) {
+  shz_ctx* ctx = t->ctx;
+  *packed = false;
+  if (t->n) return SHZ_OK;
+  if (t->ns == 0) { *packed = true; return SHZ_OK; }
+  ph_clock pc(t);
+  uint32_t mm[3];
+  SHZ_TRY(staged_minmax(t, 0, t->ns, mm));
+  pc.lap(PH_MAXES);
+  bool ok = false;
+  SHZ_TRY(run_layout(t, std::max(t->max_sid, mm[0]), std::max(t->max_off, mm[1]), &ok));
+  if (!ok) return SHZ_OK;
+  // INSERT IGNORE against the rows of frozen segments (only where song-id ranges meet)
+  SHZ_TRY(drop_staged_duplicates_of_frozen(t, mm[2], mm[0]));
+  t->max_sid = std::max(t->max_sid, mm[0]);
+  t->max_off = std::max(t->max_off, mm[1]);
+  if (n_blocks <= 1) {
+    if (t->runs.size() + 1 > KW_MAXK) SHZ_TRY(collapse_runs(t));
+    SHZ_TRY(seal_rows(t, t->skey, t->ssid, t->soff, t->ns, mm[2], mm[0]));
+  } else {
+    uint64_t o = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const uint64_t n = std::min<uint64_t>(block_rows[b], t->ns - std::min(o, t->ns));   // (the anti-join may have shortened the rows)
+      if (n) {
+        uint32_t bm[3];
+        SHZ_TRY(staged_minmax(t, o, n, bm));
+        if (t->runs.size() + 1 > KW_MAXK) SHZ_TRY(collapse_runs(t));
+        SHZ_TRY(seal_rows(t, t->skey + o, t->ssid + o, t->soff + o, n, bm[2], bm[0]));
+      }
+      o += n;
+    }
+    if (o < t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)o, (unsigned long long)t->ns);
+  }
+  t->ns = 0;
+  *packed = true;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_seal_run(shz_table* t) {
+  if (!t) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
+  if (t->ns == 0) return SHZ_OK;
+  bool packed = false;
+  SHZ_TRY(seal_staged(t, nullptr, 0, &packed));
+  if (!packed) return shz_table_finalize(t);   // rows in the active segment, or ids too wide: the column path, rows visible at once
+  while (runs_rows(t) >= std::min<uint64_t>(t->seg_limit, (1ull << 32) - 4096)) {
+    const uint64_t before = runs_rows(t);
+    SHZ_TRY(flush_runs(t, false));
+    if (runs_rows(t) >= before) break;
+  }
+  return SHZ_OK;
+}
+
+// rows gathered from every rank (or the blocks of finalize_runs) -> table.  With `c`, the sealed local rows travel as
+// ONE run per rank; all ranks pack in the layout the global maxima give.
 static int32_t build_from_runs(shz_table* t, shz_comm* c, const uint64_t* run_rows_in, uint32_t n_runs_in, uint64_t* bytes_recv) {
   shz_ctx* ctx = t->ctx;
   int rank = 0, nranks = 1;
   if (c) shz_comm_info(c, &rank, &nranks);
   t->bs_sort = t->bs_exchange = t->bs_merge = t->bs_segments = 0.0;
-  // maxima of this rank's staged rows
-  void* mx;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, 64 + 24ull * (nranks + 1), &mx));
-  SHZ_HIP(ctx, hipMemsetAsync(mx, 0, 64, ctx->stream));
-  if (t->ns)
-    hipLaunchKernelGGL(tbl_max_kernel, dim3((unsigned)std::min<uint64_t>((t->ns + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, (uint32_t*)mx);
-  SHZ_HIP(ctx, hipGetLastError());
-  uint32_t maxes[2];
-  SHZ_HIP(ctx, shz_memcpy(ctx, maxes, mx, 8, hipMemcpyDeviceToHost));
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // counts and maxima of every rank
-  std::vector<uint64_t> info(3 * (size_t)nranks, 0);
-  info[3 * (size_t)rank] = t->ns; info[3 * (size_t)rank + 1] = maxes[0]; info[3 * (size_t)rank + 2] = maxes[1];
+  if (bytes_recv) *bytes_recv = 0;
+  static const bool force_cols = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "columns"); }();
+  // this rank's rows: staged + already sealed.  Maxima first -- every rank must pack alike.
+  uint32_t mm[3] = {0u, 0u, 0xFFFFFFFFu};
+  if (t->ns) SHZ_TRY(staged_minmax(t, 0, t->ns, mm));
+  for (const shz_run& r : t->runs)
+    if (r.n) { mm[0] = std::max(mm[0], r.sid_hi); mm[2] = std::min(mm[2], r.sid_lo); }
+  const uint64_t local_off_max = std::max<uint64_t>(mm[1], t->runs.empty() ? 0 : t->max_off);   // (max_off covers every sealed run)
+  const uint64_t local_rows = t->ns + runs_rows(t);
+  // the general (column) path if ANY rank needs it: a table that already holds rows, ids + offsets too wide to pack
+  const bool local_general = t->n || !t->done.empty() || force_cols || bits_for(mm[0]) + bits_for(local_off_max) > 32;
+  std::vector<uint64_t> info(5 * (size_t)nranks, 0);
+  uint64_t* mine = &info[5 * (size_t)rank];
+  mine[0] = local_rows; mine[1] = mm[0]; mine[2] = local_off_max; mine[3] = mm[2]; mine[4] = local_general ? 1 : 0;
   if (c && nranks > 1) {
-    uint64_t* d_info = (uint64_t*)((char*)mx + 64);
-    SHZ_HIP(ctx, shz_memcpy(ctx, d_info, &info[3 * (size_t)rank], 24, hipMemcpyHostToDevice));
-    SHZ_TRY(shz_comm_allgather_bytes(c, d_info, d_info + 3, 24));
-    SHZ_HIP(ctx, shz_memcpy(ctx, info.data(), d_info + 3, 24ull * nranks, hipMemcpyDeviceToHost));
+    void* d;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 40ull * (nranks + 1), &d));
+    uint64_t* d_info = (uint64_t*)d;
+    SHZ_HIP(ctx, shz_memcpy(ctx, d_info, mine, 40, hipMemcpyHostToDevice));
+    SHZ_TRY(shz_comm_allgather_bytes(c, d_info, d_info + 5, 40));
+    SHZ_HIP(ctx, shz_memcpy(ctx, info.data(), d_info + 5, 40ull * nranks, hipMemcpyDeviceToHost));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   uint64_t total = 0, gmax_sid = 0, gmax_off = 0;
-  std::vector<uint64_t> cnt(nranks), displ(nranks);
+  bool any_general = false;
+  std::vector<uint64_t> cnt(nranks);
   for (int r = 0; r < nranks; ++r) {
-    cnt[r] = info[3 * (size_t)r];
-    displ[r] = total;
+    cnt[r] = info[5 * (size_t)r];
     total += cnt[r];
-    gmax_sid = std::max(gmax_sid, info[3 * (size_t)r + 1]);
-    gmax_off = std::max(gmax_off, info[3 * (size_t)r + 2]);
+    gmax_sid = std::max(gmax_sid, info[5 * (size_t)r + 1]);
+    gmax_off = std::max(gmax_off, info[5 * (size_t)r + 2]);
+    any_general |= info[5 * (size_t)r + 4] != 0;
   }
-  if (bytes_recv) *bytes_recv = 0;
-  const int sb = bits_for(gmax_sid), ob = bits_for(gmax_off);
-  static const bool force_cols = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "columns"); }();
+  if (bits_for(gmax_sid) + bits_for(gmax_off) > 32) any_general = true;
+  if (any_general) return SHZ_I_GENERAL_PATH;
   if (total == 0) return shz_table_finalize(t);
-  if (sb + ob > 32 || t->n || !t->done.empty() || force_cols) return SHZ_I_GENERAL_PATH;
-  // 1) local runs: the staged rows of this rank as sorted packed runs, back to back
-  std::vector<uint64_t> my_runs;
-  if (c) my_runs.push_back(t->ns);
-  else my_runs.assign(run_rows_in, run_rows_in + n_runs_in);
-  uint64_t sum = 0;
-  for (uint64_t r : my_runs) sum += r;
-  if (sum != t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)sum, (unsigned long long)t->ns);
+  // 1) local rows -> sorted run(s) in the agreed layout
   double t0 = now_s();
-  void *pa, *pb;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, std::max<uint64_t>(t->ns, 1) * 8, &pa));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, std::max<uint64_t>(t->ns, 1) * 8, &pb));
-  uint64_t o = 0;
-  for (uint64_t r : my_runs) {
-    SHZ_TRY(pack_sort_run(ctx, t->skey + o, t->ssid + o, t->soff + o, r, sb, ob, (uint64_t*)pa + o, (uint64_t*)pb + o));
-    o += r;
-  }
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  t->bs_sort = now_s() - t0;
-  // the staged columns have done their work: release them before the gathered buffers are allocated
-  void* olds[] = {t->skey, t->ssid, t->soff};
-  for (void* p : olds)
-    if (p) SHZ_HIP(ctx, hipFree(p));
-  t->skey = t->ssid = t->soff = nullptr;
-  const uint64_t ns_local = t->ns;
-  t->ns = t->scap = 0;
-  // 2) exchange: every rank's run(s) into one buffer at the rank's displacement
-  uint64_t *ga = nullptr, *gb = nullptr;
-  struct guard { uint64_t** p[2]; ~guard() { for (auto q : p) if (*q) (void)hipFree(*q); } } gd{{&ga, &gb}};
-  std::vector<uint64_t> run_off{0};
-  t0 = now_s();
-  if (c && nranks > 1) {
-    if (hipMalloc(&ga, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "allgather: hipMalloc(%llu) failed", (unsigned long long)(total * 8));
-    std::vector<uint64_t> bcnt(nranks), bdis(nranks);
-    for (int r = 0; r < nranks; ++r) { bcnt[r] = cnt[r] * 8; bdis[r] = displ[r] * 8; run_off.push_back(displ[r] + cnt[r]); }
-    SHZ_TRY(shz_comm_allgatherv_bytes(c, pa, ga, bcnt.data(), bdis.data()));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (bytes_recv) *bytes_recv = (total - ns_local) * 8;
-  } else {
-    if (hipMalloc(&ga, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "hipMalloc(%llu) failed", (unsigned long long)(total * 8));
-    SHZ_HIP(ctx, hipMemcpyAsync(ga, pa, total * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    uint64_t acc = 0;
-    for (uint64_t r : my_runs) { acc += r; run_off.push_back(acc); }
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  t->bs_exchange = now_s() - t0;
-  // 3) merge the runs
-  t0 = now_s();
-  uint64_t* g = ga;
-  if (run_off.size() > 2) {
-    if (hipMalloc(&gb, total * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "merge: hipMalloc(%llu) failed", (unsigned long long)(total * 8));
-    SHZ_TRY(merge_runs(ctx, ga, gb, run_off, &g));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t** other = (g == ga) ? &gb : &ga;   // the buffer that does not hold the result goes before the columns come
-    (void)hipFree(*other);
-    *other = nullptr;
-  }
-  t->bs_merge = now_s() - t0;
-  // 4) segments
-  t0 = now_s();
+  bool ok = false;
+  SHZ_TRY(run_layout(t, (uint32_t)gmax_sid, (uint32_t)gmax_off, &ok));
   t->max_sid = std::max<uint32_t>(t->max_sid, (uint32_t)gmax_sid);
   t->max_off = std::max<uint32_t>(t->max_off, (uint32_t)gmax_off);
-  SHZ_TRY(segments_from_sorted(t, g, total, sb, ob));
+  if (t->ns) {
+    bool packed = false;
+    if (!c && n_runs_in) {
+      uint64_t sum = 0;
+      for (uint32_t i = 0; i < n_runs_in; ++i) sum += run_rows_in[i];
+      if (sum != t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)sum, (unsigned long long)t->ns);
+    }
+    SHZ_TRY(seal_staged(t, c ? nullptr : run_rows_in, c ? 0 : n_runs_in, &packed));
+    if (!packed) SHZ_FAIL(ctx, SHZ_E_STATE, "build_from_runs: rows could not be packed");
+  }
+  if (!c || nranks == 1) {
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->bs_sort = now_s() - t0;
+    t0 = now_s();
+    const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE], s0 = t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET];
+    SHZ_TRY(flush_runs(t, true));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->bs_merge = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE] - m0;
+    t->bs_segments = std::max(now_s() - t0 - t->bs_merge, t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET] - s0);
+    return SHZ_OK;
+  }
+  SHZ_TRY(collapse_runs(t));   // one run per rank travels
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  t->bs_segments = now_s() - t0;
+  t->bs_sort = now_s() - t0;
+  // duplicates inside the local run are gone; what the other ranks hold is what they counted BEFORE their own dedup, so
+  // the run lengths are exchanged again (8 bytes a rank)
+  const uint64_t my_rows = runs_rows(t);
+  {
+    void* d;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d));
+    SHZ_HIP(ctx, shz_memcpy(ctx, d, &my_rows, 8, hipMemcpyHostToDevice));
+    SHZ_TRY(shz_comm_allgather_bytes(c, d, (uint64_t*)d + 1, 8));
+    SHZ_HIP(ctx, shz_memcpy(ctx, cnt.data(), (uint64_t*)d + 1, 8ull * nranks, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // 2) exchange: every rank's run lands behind this rank's own in the run arena, 256-byte aligned
+  t0 = now_s();
+  std::vector<uint64_t> displ(nranks), bcnt(nranks), bdis(nranks);
+  const uint64_t src_off = t->runs.empty() ? 0 : t->runs[0].off;
+  uint64_t at = (src_off + my_rows + 31) & ~31ull;
+  total = 0;
+  for (int r = 0; r < nranks; ++r) {
+    displ[r] = at;
+    at = (at + cnt[r] + 31) & ~31ull;
+    total += cnt[r];
+    if (cnt[r] >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "rank %d holds %llu rows (a run is limited to < 2^32)", r, (unsigned long long)cnt[r]);
+  }
+  SHZ_TRY(rbuf_reserve(t, at));
+  const uint64_t g0 = displ[0];
+  for (int r = 0; r < nranks; ++r) { bcnt[r] = cnt[r] * 8; bdis[r] = (displ[r] - g0) * 8; }
+  SHZ_TRY(shz_comm_allgatherv_bytes(c, t->rbuf + src_off, t->rbuf + g0, bcnt.data(), bdis.data()));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (bytes_recv) *bytes_recv = (total - my_rows) * 8;
+  t->bs_exchange = now_s() - t0;
+  // 3) the gathered runs replace the local one; rank r's rows carry the song ids rank r reported
+  t->runs.clear();
+  for (int r = 0; r < nranks; ++r)
+    if (cnt[r]) t->runs.push_back(shz_run{displ[r], cnt[r], (uint32_t)info[5 * (size_t)r + 3], (uint32_t)info[5 * (size_t)r + 1]});
+  while (t->runs.size() > KW_MAXK) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d ranks", KW_MAXK);
+  t0 = now_s();
+  const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE];
+  SHZ_TRY(flush_runs(t, true));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->bs_merge = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE] - m0;
+  t->bs_segments = now_s() - t0 - t->bs_merge;
   return SHZ_OK;
 }
 
@@ -1208,6 +1957,7 @@ static int32_t allgather_columns(shz_table* t, shz_comm* c, uint64_t* bytes_recv
     if (p) SHZ_HIP(ctx, hipFree(p));
   t->skey = gc.take(0); t->ssid = gc.take(1); t->soff = gc.take(2);
   t->ns = t->scap = total;
+  t->stage_reserved = false;
   const double t1 = now_s();
   const int32_t rc = shz_table_finalize(t);
   t->bs_segments = now_s() - t1;
@@ -1242,7 +1992,9 @@ extern "C" int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* e
 }
 
 static const char* const k_phase_names[] = {"stage_alloc", "insert", "dedup_frozen", "topup", "maxes", "sort", "merge", "uniq_scan",
-                                            "column_alloc", "compact", "bucket", "slice", "stage_free"};
+                                            "column_alloc", "compact", "bucket", "slice", "stage_free", "run_pack", "run_sort", "run_uniq",
+                                            "kway_plan", "kway_merge", "reserve_wait"};
+static_assert(sizeof(k_phase_names) / sizeof(k_phase_names[0]) == PH_COUNT, "one name per phase");
 extern "C" int32_t shz_table_phase_stats(shz_table* t, double* seconds, uint32_t cap, uint32_t* n, int32_t reset) {
   if (!t) return SHZ_E_INVALID;
   const uint32_t np = (uint32_t)(sizeof(k_phase_names) / sizeof(k_phase_names[0]));
@@ -1416,6 +2168,7 @@ extern "C" int32_t shz_table_shard_exchange(shz_table* t, shz_comm* c, uint64_t*
   for (void* p : olds)
     if (p) SHZ_HIP(ctx, hipFree(p));
   t->skey = rcvc.take(0); t->ssid = rcvc.take(1); t->soff = rcvc.take(2);  // the send columns go with sndc
+  t->stage_reserved = false;
   t->ns = total;
   t->scap = std::max<uint64_t>(total, 1);
   SHZ_TRY(shz_table_finalize(t));

@@ -208,6 +208,16 @@ extern "C" int32_t shz_device_info(shz_ctx* ctx, char* name, uint64_t name_cap, 
   return SHZ_OK;
 }
 
+extern "C" int32_t shz_mem_info(shz_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!ctx) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  SHZ_HIP(ctx, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_dev_alloc(shz_ctx* ctx, uint64_t bytes, void** dptr) {
   if (!ctx || !dptr) return SHZ_E_INVALID;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));

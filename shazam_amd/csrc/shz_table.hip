@@ -1536,7 +1536,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                           uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs, pair_sink* vs_out) {
   if (!ctx || !t) return SHZ_E_INVALID;
   if (t->ctx != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "table belongs to another ctx");
-  if (t->ns || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
+  if (pending_rows(t) || (!t->bucket && t->done.empty())) SHZ_FAIL(ctx, SHZ_E_STATE, "table not finalized");
   if (n_queries == 0) return SHZ_OK;
   if (!query_off) SHZ_FAIL(ctx, SHZ_E_INVALID, "match: query_off is NULL");
   if (!vs_out && (!out_sid || !out_delta || !out_aligned || !out_dedup || !out_nres))

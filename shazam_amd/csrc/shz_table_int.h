@@ -13,6 +13,8 @@
 struct shz_seg {
   uint32_t *key, *sid, *off, *bucket;
   uint64_t n, nbuckets;
+  uint32_t sid_lo = 0, sid_hi = 0xFFFFFFFFu;   // song ids the segment may hold (conservative, inclusive)
+  bool slab = false;                           // columns carved from the table's slab: never freed on their own
 };
 struct shz_seg_dev {  // what the match kernels see
   const uint32_t *key, *sid, *off, *bucket;
@@ -21,7 +23,15 @@ struct shz_seg_dev {  // what the match kernels see
 };
 #define SHZ_MAX_SEGS 32
 
-#define SHZ_TABLE_PHASES 16
+#define SHZ_TABLE_PHASES 24
+
+// a sorted run of packed rows (key << (sb + ob) | sid << ob | off) waiting in the run arena for the k-way merge
+struct shz_run {
+  uint64_t off, n;             // position / rows in shz_table::rbuf
+  uint32_t sid_lo, sid_hi;     // song ids of the run: runs with disjoint ranges cannot hold the same row
+};
+struct shz_reserve_job;        // background allocation of the arenas (shz_table_reserve)
+
 struct shz_table {
   shz_ctx* ctx = nullptr;
   std::vector<shz_seg> done;           // frozen segments
@@ -37,12 +47,24 @@ struct shz_table {
   double bs_sort = 0, bs_exchange = 0, bs_merge = 0, bs_segments = 0;   // seconds of the last run-merge build
   bool broken = false;  // a finalize ran out of memory after giving up the old columns: rows were lost, refuse further use
   double ph[SHZ_TABLE_PHASES] = {0};   // host seconds per build phase since the last reset (shz_table_phase_stats)
+  // ---- bulk build: staged rows become sorted runs, runs become segments in one k-way merge (shz_build.hip)
+  uint32_t act_sid_lo = 0, act_sid_hi = 0xFFFFFFFFu;   // song ids of the active segment
+  bool act_slab = false;                                // the active columns are carved from the slab
+  char* slab = nullptr;                                 // ONE allocation the segments' columns are carved from
+  uint64_t slab_bytes = 0, slab_used = 0;
+  uint64_t* rbuf = nullptr;                             // run arena
+  uint64_t rcap = 0;                                    // ... rows it holds
+  std::vector<shz_run> runs;
+  int run_sb = 0, run_ob = 0;                           // packing of the runs (0: none yet)
+  bool stage_reserved = false;                          // the staging columns were sized by shz_table_reserve: kept
+  shz_reserve_job* job = nullptr;
 };
 
 // phases of the single-GPU build, in the order shz_table_phase_stats reports them
 enum { PH_STAGE_ALLOC = 0, PH_INSERT, PH_DEDUP_FROZEN, PH_TOPUP, PH_MAXES, PH_SORT, PH_MERGE, PH_UNIQ, PH_COL_ALLOC, PH_COMPACT,
-       PH_BUCKET, PH_SLICE, PH_STAGE_FREE };
-static_assert(PH_STAGE_FREE < SHZ_TABLE_PHASES, "phase table too small");
+       PH_BUCKET, PH_SLICE, PH_STAGE_FREE, PH_RUN_PACK, PH_RUN_SORT, PH_RUN_UNIQ, PH_KW_PLAN, PH_KW_MERGE, PH_RESERVE_WAIT,
+       PH_COUNT };
+static_assert(PH_COUNT <= SHZ_TABLE_PHASES, "phase table too small");
 static inline double now_s() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -64,12 +86,19 @@ struct ph_clock {
 
 static inline std::vector<shz_seg> all_segs(const shz_table* t) {
   std::vector<shz_seg> v = t->done;
-  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets});
+  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab});
   return v;
 }
 static inline uint64_t total_rows(const shz_table* t) {
   uint64_t n = t->n;
   for (const shz_seg& g : t->done) n += g.n;
+  return n;
+}
+
+// rows inserted but not yet visible to queries: staged columns + sealed runs
+static inline uint64_t pending_rows(const shz_table* t) {
+  uint64_t n = t->ns;
+  for (const shz_run& r : t->runs) n += r.n;
   return n;
 }
 
@@ -94,6 +123,7 @@ struct dev_cols {
   uint32_t* take(int i) { uint32_t* q = p[i]; p[i] = nullptr; return q; }
 };
 
+static inline bool ranges_overlap(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi) { return a_lo <= b_hi && b_lo <= a_hi; }
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 // shard of a key: a different multiplier and bit field than slice_of (segments inside a shard stay balanced)

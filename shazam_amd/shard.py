@@ -131,6 +131,13 @@ class ShardedTable:
             for t in self.tables:
                 t.finalize()
 
+    def seal_run(self):
+        """Bound the staged rows of a long build (shz_table_seal_run on every local shard; with a communicator the rows
+        stay staged until the exchange)."""
+        if self.comm is None:
+            for t in self.tables:
+                t.seal_run()
+
     def delete_songs(self, sids) -> int:
         """ON DELETE CASCADE on every shard held here (with a communicator: call it on every rank)."""
         return sum(t.delete_songs(sids) for t in self.tables)
