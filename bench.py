@@ -43,18 +43,54 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measu
 PCM_BYTES_PER_FRAME = 4096               # 2,048 new int16 samples per frame
 # bytes each kernel itself moves per frame with fp32 staging (the default; fp64 staging doubles the 2049-bin rows)
 STAGED_BYTES_PER_FRAME = {"stft_psd": 4096 + 2049 * 4, "peak_pick": 2049 * 4 + 288}
-PMC_PROFILE = "r02_pmc_traffic.json"
+FP64_VALU_PEAK_TFLOPS = 78.6                    # MI355X vector fp64 peak (MI355X_MICROARCH.md)
+FFT_FLOP_PER_FRAME = 2.5 * 4096 * 12            # 2.5 N log2 N of the real 4096-point transform
 PMC_KERNELS = {"stft_psd": "stft_psd_kernel<float>", "peak_pick": "peak_pick32_kernel<2, 4>"}
 
 
+def newest_profile(suffix):
+    """The newest committed profiles/r<NN><x>_<suffix> (names sort by round, then by letter)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))
+        if m:
+            key = (int(m.group(1)), m.group(2))
+            if best is None or key > best[0]:
+                best = (key, f)
+    return best[1] if best else None
+
+
+def pmc_kernel(prof, kernel):
+    for name, rec in prof["kernels"].items():
+        if name.startswith(PMC_KERNELS[kernel].split("<")[0]):
+            return rec
+    return None
+
+
 def pmc_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), scaled to this
-    run's frames per launch; None when no profile of that kernel is committed."""
+    """(HBM GB per launch of `kernel`, profile file) from the newest committed rocprofv3 PMC passes (profiles/), scaled to
+    this run's frames per launch; (None, None) when no profile of that kernel is committed."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
-        return prof["kernels"][PMC_KERNELS[kernel]]["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000)
+        f = newest_profile("pmc_traffic.json")
+        prof = json.load(open(f))
+        rec = pmc_kernel(prof, kernel)
+        return rec["hbm_bytes_corrected"] / 1e9 * frames_per_launch / prof.get("frames_per_launch", 644000), os.path.basename(f)
     except Exception:
-        return None
+        return None, None
+
+
+def pmc_valu_busy(kernel, waves_per_simd=3.0):
+    """(fraction of issue cycles in which a SIMD's VALU is busy, profile file) from the newest committed SQ counter passes:
+    frac_valu = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of a WAVE's cycles spent issuing VALU work; stft_psd runs
+    3 workgroups x 4 waves per CU = 3 waves per SIMD (__launch_bounds__(256, 3)), so the SIMD is busy 3 x that."""
+    try:
+        f = newest_profile("pmc_counters.json")
+        rec = pmc_kernel(json.load(open(f)), kernel)
+        return min(1.0, rec["frac_valu"] * waves_per_simd), os.path.basename(f)
+    except Exception:
+        return None, None
 
 
 def cpu_worker(args):
@@ -166,6 +202,15 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
                        "collective": (f"RCCL all-gather-v of the ranks' sorted packed runs (8 B/row, pieces <= 1 GB, "
                                       f"pattern {os.environ.get('SHZ_ALLGATHER', 'sendrecv')}), then {world}-way merge") if comm else None,
                        "build_stats_s": tbl.build_stats() if comm else None}
+    # STRONG scaling of the database build (north star: >= 6x at 8 GPUs): ONE fixed corpus, the same at every N, split in
+    # contiguous blocks (ingest.shard_tracks), fingerprint -> RCCL all-gather of the sorted runs -> k-way merge -> table.
+    # N = 1 runs the same code with one run and no exchange.  The reference's analogue is the file-level Pool of
+    # fingerprint_directory (__init__.py:335-357).
+    if a.scaling_songs > 0:
+        try:
+            out["db_build_scaling"] = db_build_scaling(a, ctx, dist, comm, rank, world)
+        except Exception as e:  # noqa: BLE001
+            out["db_build_scaling"] = {"error": repr(e)}
     # batched recognise: hop-aligned 5 s crops of this rank's own tracks (clean; SNR mixing is a test-side path)
     nq = min(a.queries, nc)
     qn = 220500
@@ -243,6 +288,70 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
         ctx2.close()
 
 
+def db_build_scaling(a, ctx, dist, comm, rank, world):
+    """Fixed corpus of a.scaling_songs x 30 s tracks split over the ranks; seconds from the first fingerprint call to the
+    node-global table standing on every GPU (max over ranks), PCM synthesis (the stand-in for audio decoding) excluded."""
+    import bench_db
+    from shazam_amd import _ffi, Table
+    from shazam_amd.ingest import shard_tracks
+    songs, seconds, chunk = a.scaling_songs, 30.0, 1000
+    n_samples = int(round(seconds * FS))
+    frames = int(_ffi.lib().shz_frame_count(n_samples))
+    lo, hi = shard_tracks(songs, rank, world)
+    rows_total = int(songs * frames * bench_db.ROWS_PER_FRAME_HINT)
+    rows_local = int((hi - lo) * frames * bench_db.ROWS_PER_FRAME_HINT)
+    tbl = Table(ctx)
+    tbl.reserve(rows_total, rows_local, gather=world > 1)
+    cap = chunk * frames * 24 + 1024
+    kbuf, tbuf, pcm = ctx.alloc(cap * 4), ctx.alloc(cap * 4), ctx.alloc(chunk * n_samples * 2)
+    if dist:
+        dist.barrier()
+    ctx.sync()
+    t_synth = t_fp = t_ins = 0.0
+    t_all0 = time.perf_counter()
+    for c0 in range(lo, hi, chunk):
+        n = min(chunk, hi - c0)
+        t0 = time.perf_counter()
+        ctx.synth_pcm(bench_db.SEED_TRACKS, c0, n, n_samples, 4000, 1500, out=pcm)
+        ctx.sync()
+        t1 = time.perf_counter()
+        _, _, ho, _ = ctx.fingerprint_batch(pcm, np.arange(n + 1, dtype=np.uint64) * n_samples, fs=FS, pcm_device=True,
+                                            out_key=kbuf, out_t1=tbuf, cap=cap)
+        ctx.sync()
+        t2 = time.perf_counter()
+        tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
+        t3 = time.perf_counter()
+        t_synth += t1 - t0
+        t_fp += t2 - t1
+        t_ins += t3 - t2
+    t0 = time.perf_counter()
+    recv = tbl.allgather(comm) if comm else 0
+    if not comm:
+        tbl.finalize()
+    ctx.sync()
+    t_table = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    t_wall = time.perf_counter() - t_all0
+    vals = [t_wall - t_synth, t_fp, t_ins + t_table, t_synth]
+    if dist:
+        import torch
+        tt = torch.tensor(vals, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        vals = [float(x) for x in tt]
+    rows, _ = tbl.rows()
+    o = {"songs": songs, "clip_seconds": seconds, "n_gpus": world, "scaling": "strong", "seconds": vals[0],
+         "songs_per_s": songs / vals[0], "audio_s_per_s": songs * seconds / vals[0], "fingerprint_s": vals[1],
+         "table_s": vals[2], "synth_s_excluded": vals[3], "rows": int(rows), "segments": int(tbl.segments()),
+         "allgather_bytes_received": int(recv), "build_stats_s": tbl.build_stats(),
+         "phases_s": {k: round(v, 4) for k, v in tbl.phase_stats().items() if v > 5e-4},
+         "note": "seconds = max over ranks of (first fingerprint call .. table standing) minus PCM synthesis; the same corpus at every N"}
+    tbl.close()
+    for b_ in (kbuf, tbuf, pcm):
+        b_.free()
+    return o
+
+
 def single_query_latency(ctx, tbl, rank, nc, n_samples, n_iter=60):
     """p50 / p99 of ONE 5 s query: fingerprint (host int16 in) + match (top-2) per call, against the step's table."""
     track = ctx.synth_pcm(1234, rank * nc + 7, 1, n_samples, 0, 8000)   # the step's track 7, synthesised on the device
@@ -285,7 +394,7 @@ def match_1m(ctx, songs, info):
     n_samples = 30 * FS
     qn = 10 * FS
     o = {"songs": songs, "rows": build["rows"], "build_seconds": build["seconds_total"],
-         "build": {k: build[k] for k in ("fingerprint_s", "insert_s", "finalize_s", "songs_per_s")},
+         "build": {k: build[k] for k in ("fingerprint_s", "insert_s", "finalize_s", "songs_per_s", "segments", "phases_s")},
          "query_seconds": 10.0, "snr_db": 10.0}
     for bs, nq in ((1, 60), (200, 2000)):
         bench_db.run_queries(ctx, tbl, songs, n_samples, bs * 2, qn, 10.0, bs, 2, seed=5)   # warm the workspace
@@ -337,6 +446,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--queries", type=int, default=2000)
     ap.add_argument("--match-songs", type=int, default=1000000, help="tracks of the match_1M extra (0 = skip)")
+    ap.add_argument("--scaling-songs", type=int, default=100000, help="fixed corpus of the db_build_scaling extra: the same "
+                    "at every --gpus N (0 = skip)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -413,9 +524,18 @@ def main():
     achieved = frames_per_launch * alg_bytes_per_frame / (avg_ms * 1e-3) / 1e9
     staged = frames_per_launch * STAGED_BYTES_PER_FRAME[dom] / (avg_ms * 1e-3) / 1e9
     step_alg = frames_per_step * alg_bytes_per_frame / (elapsed / a.steps) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, frames_per_launch),
-                "traffic_unit": f"GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{PMC_PROFILE})",
+    traffic, traffic_file = pmc_traffic(dom, frames_per_launch)
+    valu_busy, valu_file = pmc_valu_busy(dom)
+    tflops = frames_per_launch * FFT_FLOP_PER_FRAME / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "valu_fp64" if dom == "stft_psd" else "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": f"GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_file})",
+                "compute": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "compute_frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                            "accounting": f"{FFT_FLOP_PER_FRAME:.0f} flop/frame (2.5 N log2 N, N = 4096) x {frames_per_launch:.0f} "
+                                          f"frames/launch / {avg_ms:.3f} ms; the kernel's own count is higher (window, split pass, |X|^2)",
+                            "valu_busy_frac_pmc": valu_busy,
+                            "valu_busy_source": f"SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 3 waves per SIMD, profiles/{valu_file}"} if dom == "stft_psd" else None,
                 "accounting": f"algorithmic bytes (SURVEY 8d): {alg_bytes_per_frame:.0f} B/frame (4096 B PCM + 8 B x "
                               f"{n_hashes / frames_per_step:.1f} hashes) x {frames_per_launch:.0f} frames/launch / "
                               f"{avg_ms:.3f} ms avg launch of {dom} (HIP events, {dom_launches} launches in the timed region)",
@@ -426,8 +546,9 @@ def main():
                 "host_overhead_ms_per_step": elapsed / a.steps * 1e3 - sum(v[0] for v in kms.values()) / a.steps,
                 "pipelines": "two halves of the batch run as two passes on two streams (SHZ_DUAL=0: one): kernel durations "
                              "overlap, their sum exceeds the step and host_overhead goes negative" if os.environ.get("SHZ_DUAL", "0") not in ("", "0") else "one",
-                "note": "the path is VALU/LDS-bound, not HBM-bound (SURVEY 8d: 30 flop/B fused): frac is small by "
-                        "construction; staged_frac is the kernel's own I/O rate"}
+                "note": "the dominant kernel is bound by fp64 VALU issue + LDS exchange, not by HBM (SURVEY 8d: 30 flop/B fused): "
+                        "achieved / frac stay the ALGORITHMIC bytes over the HBM peak as the contract defines them, "
+                        "compute.compute_frac is the ceiling the kernel is actually up against; staged_frac is its own I/O rate"}
 
     out = {"metric": "audio_seconds_fingerprinted_per_second", "value": value, "unit": "audio-s/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
@@ -470,7 +591,8 @@ def main():
             try:
                 for b_ in (kbuf, tbuf, pcm):
                     b_.free()
-                ctx.release_workspace()
+                # (the workspace and the blocks earlier tables handed back stay with the context: memory that went through
+                # hipFree comes back scrubbed by the driver at ~40 GB/s on its next use)
                 out["match_1M"] = match_1m(ctx, a.match_songs, info)
             except Exception as e:  # noqa: BLE001
                 out["match_1M"] = {"error": repr(e)}

@@ -198,9 +198,17 @@ extern "C" int32_t shz_table_destroy(shz_table* t) {
   (void)hipStreamSynchronize(t->ctx->stream);
   reserve_cancel(t);
   free_cols(t->act_slab, t->key, t->sid, t->off);
-  void* ps[] = {t->skey, t->ssid, t->soff, t->bucket, t->rbuf, t->slab};
-  for (void* p : ps)
-    if (p) (void)hipFree(p);
+  if (t->stage_reserved) {
+    uint32_t* st[3] = {t->skey, t->ssid, t->soff};
+    for (int i = 0; i < 3; ++i) shz_block_free(t->ctx, st[i], t->st_bytes[i]);
+  } else {
+    void* st[] = {t->skey, t->ssid, t->soff};
+    for (void* p : st)
+      if (p) (void)hipFree(p);
+  }
+  if (t->bucket) (void)hipFree(t->bucket);
+  shz_block_free(t->ctx, t->rbuf, t->rbuf_bytes);
+  shz_block_free(t->ctx, t->slab, t->slab_bytes);
   for (shz_seg& g : t->done) {
     free_cols(g.slab, g.key, g.sid, g.off);
     if (g.bucket) (void)hipFree(g.bucket);
@@ -233,6 +241,7 @@ static int32_t stage_reserve(shz_table* t, uint64_t extra) {
     *old[i] = np[i];
   }
   t->scap = cap;
+  t->stage_reserved = false;   // plain allocations from here on
   return SHZ_OK;
 }
 
@@ -1059,12 +1068,15 @@ struct shz_reserve_job {
   std::condition_variable cv;
   int done = 0;                  // allocations finished so far (1: staging, 2: run arena + sort scratch, 3: slab)
   int device = 0;
+  shz_ctx* ctx = nullptr;
   uint64_t stage_rows = 0, run_rows = 0, slab_bytes = 0, sort_bytes = 0;
+  uint64_t st_bytes[3] = {0, 0, 0}, rbuf_bytes = 0;   // real sizes of the blocks (a cached block may be larger)
   uint32_t* st[3] = {nullptr, nullptr, nullptr};
   uint64_t* rbuf = nullptr;
   void* sortbuf[2] = {nullptr, nullptr};
   char* slab = nullptr;
   bool failed = false;
+  double alloc_s = 0.0;          // seconds the helper thread spent inside hipMalloc
 };
 enum { RJ_STAGE = 1, RJ_RUNS = 2, RJ_SLAB = 3 };
 
@@ -1074,16 +1086,20 @@ static void reserve_cancel(shz_table* t) {   // the table goes away (or starts o
 
 static void reserve_worker(shz_reserve_job* j) {
   (void)hipSetDevice(j->device);
-  auto step = [&](int n) { std::lock_guard<std::mutex> lk(j->mu); j->done = n; j->cv.notify_all(); };
+  const double t0 = now_s();
+  auto step = [&](int n) { std::lock_guard<std::mutex> lk(j->mu); j->done = n; j->alloc_s = now_s() - t0; j->cv.notify_all(); };
   bool ok = true;
-  for (auto& q : j->st) ok = ok && j->stage_rows && hipMalloc(&q, j->stage_rows * 4) == hipSuccess;
-  if (!ok) { for (auto& q : j->st) { if (q) (void)hipFree(q); q = nullptr; } (void)hipGetLastError(); }
+  for (int i = 0; i < 3; ++i) ok = ok && j->stage_rows && shz_block_alloc(j->ctx, j->stage_rows * 4, (void**)&j->st[i], &j->st_bytes[i]) == hipSuccess;
+  if (!ok) { for (int i = 0; i < 3; ++i) { if (j->st[i]) shz_block_free(j->ctx, j->st[i], j->st_bytes[i]); j->st[i] = nullptr; } (void)hipGetLastError(); }
   step(RJ_STAGE);
-  if (j->run_rows && hipMalloc(&j->rbuf, j->run_rows * 8) != hipSuccess) { j->rbuf = nullptr; (void)hipGetLastError(); }
+  if (j->run_rows && shz_block_alloc(j->ctx, j->run_rows * 8, (void**)&j->rbuf, &j->rbuf_bytes) != hipSuccess) { j->rbuf = nullptr; (void)hipGetLastError(); }
   for (auto& q : j->sortbuf)
     if (j->sort_bytes && hipMalloc(&q, j->sort_bytes) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
   step(RJ_RUNS);
-  if (j->slab_bytes && hipMalloc(&j->slab, j->slab_bytes) != hipSuccess) { j->slab = nullptr; j->failed = true; (void)hipGetLastError(); }
+  if (j->slab_bytes) {
+    const uint64_t want = j->slab_bytes;
+    if (shz_block_alloc(j->ctx, want, (void**)&j->slab, &j->slab_bytes) != hipSuccess) { j->slab = nullptr; j->failed = true; (void)hipGetLastError(); }
+  }
   step(RJ_SLAB);
 }
 
@@ -1100,11 +1116,12 @@ static void reserve_wait(shz_table* t, int which) {
   if (j->st[0] && t->ns == 0 && !t->skey) {
     t->skey = j->st[0]; t->ssid = j->st[1]; t->soff = j->st[2];
     t->scap = j->stage_rows;
+    for (int i = 0; i < 3; ++i) t->st_bytes[i] = j->st_bytes[i];
     t->stage_reserved = true;
     j->st[0] = j->st[1] = j->st[2] = nullptr;
   }
   if (which >= RJ_RUNS) {
-    if (j->rbuf && !t->rbuf) { t->rbuf = j->rbuf; t->rcap = j->run_rows; j->rbuf = nullptr; }
+    if (j->rbuf && !t->rbuf) { t->rbuf = j->rbuf; t->rcap = j->run_rows; t->rbuf_bytes = j->rbuf_bytes; j->rbuf = nullptr; }
     const int slots[2] = {SHZ_WS_SORT_A, SHZ_WS_SORT_B};
     for (int i = 0; i < 2; ++i)
       if (j->sortbuf[i]) {
@@ -1122,8 +1139,9 @@ static void reserve_wait(shz_table* t, int which) {
   if (which >= RJ_SLAB) {
     if (j->slab && !t->slab) { t->slab = j->slab; t->slab_bytes = j->slab_bytes; t->slab_used = 0; j->slab = nullptr; }
     j->th.join();
-    for (auto& q : j->st) if (q) (void)hipFree(q);
-    if (j->rbuf) (void)hipFree(j->rbuf);
+    t->ph[PH_RESERVE_ALLOC] += j->alloc_s;
+    for (int i = 0; i < 3; ++i) if (j->st[i]) shz_block_free(ctx, j->st[i], j->st_bytes[i]);
+    if (j->rbuf) shz_block_free(ctx, j->rbuf, j->rbuf_bytes);
     delete j;
     t->job = nullptr;
   }
@@ -1140,6 +1158,7 @@ extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t 
   batch_rows_hint = std::min<uint64_t>(batch_rows_hint, (1ull << 32) - 4096);
   shz_reserve_job* j = new shz_reserve_job();
   j->device = ctx->device;
+  j->ctx = ctx;
   j->stage_rows = t->skey ? 0 : batch_rows_hint + batch_rows_hint / 16 + 1024;
   // run arena: what is merged at once.  One GPU: a segment's worth of runs + the batch being sealed + the remainder a
   // flush leaves; the gathered build (SHZ_RESERVE_GATHER): this rank's run beside every rank's.
@@ -1152,13 +1171,21 @@ extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t 
   size_t mem_free = 0, mem_total = 0;
   SHZ_HIP(ctx, hipMemGetInfo(&mem_free, &mem_total));
   const uint64_t want = j->slab_bytes + j->run_rows * 8 + j->stage_rows * 12 + 2 * j->sort_bytes;
-  if (want > (uint64_t)mem_free - ((uint64_t)mem_free >> 4)) {
+  uint64_t avail = mem_free;   // + what the context keeps from earlier tables (reused where it fits, dropped where it does not)
+  {
+    std::lock_guard<std::mutex> lk(ctx->blocks_mu);
+    for (const shz_buf& b : ctx->blocks) avail += b.cap;
+  }
+  avail += ctx->ws[SHZ_WS_SORT_A].cap + ctx->ws[SHZ_WS_SORT_B].cap;
+  if (want > avail - (avail >> 4)) {
     delete j;
     SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_table_reserve: %llu rows need %.1f GB of device memory, %.1f GB are free",
-             (unsigned long long)rows_hint, want / 1e9, mem_free / 1e9);
+             (unsigned long long)rows_hint, want / 1e9, avail / 1e9);
   }
   t->job = j;
   j->th = std::thread(reserve_worker, j);
+  static const bool sync_alloc = [] { const char* e = getenv("SHZ_RESERVE_SYNC"); return e && atoi(e) != 0; }();
+  if (sync_alloc) reserve_wait(t, RJ_SLAB);   // measurement aid: the allocations on the caller's clock, nothing beside them
   return SHZ_OK;
 }
 
@@ -1193,9 +1220,10 @@ static int32_t rbuf_reserve(shz_table* t, uint64_t rows) {
   if (hipMalloc(&nb, cap * 8) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "run arena: hipMalloc(%llu) failed", (unsigned long long)(cap * 8));
   if (used) SHZ_HIP(ctx, hipMemcpyAsync(nb, t->rbuf, used * 8, hipMemcpyDeviceToDevice, ctx->stream));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (t->rbuf) SHZ_HIP(ctx, hipFree(t->rbuf));
+  if (t->rbuf) shz_block_free(ctx, t->rbuf, t->rbuf_bytes);
   t->rbuf = nb;
   t->rcap = cap;
+  t->rbuf_bytes = cap * 8;
   return SHZ_OK;
 }
 
@@ -1554,14 +1582,12 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
   if (rest_rows) *rest_rows = 0;
   kw_runs R;
   memset(&R, 0, sizeof(R));
-  uint64_t total = 0;
   uint32_t k = 0, sid_lo = 0xFFFFFFFFu, sid_hi = 0;
   for (size_t i = 0; i < runs.size(); ++i) {
     if (!runs[i].n) continue;
     if (k == KW_MAXK) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "k-way merge of more than %d runs", KW_MAXK);
     R.p[k] = ptr[i];
     R.n[k] = (uint32_t)runs[i].n;
-    total += runs[i].n;
     sid_lo = std::min(sid_lo, runs[i].sid_lo);
     sid_hi = std::max(sid_hi, runs[i].sid_hi);
     ++k;
@@ -1993,7 +2019,7 @@ extern "C" int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* e
 
 static const char* const k_phase_names[] = {"stage_alloc", "insert", "dedup_frozen", "topup", "maxes", "sort", "merge", "uniq_scan",
                                             "column_alloc", "compact", "bucket", "slice", "stage_free", "run_pack", "run_sort", "run_uniq",
-                                            "kway_plan", "kway_merge", "reserve_wait"};
+                                            "kway_plan", "kway_merge", "reserve_wait", "reserve_alloc_thread"};
 static_assert(sizeof(k_phase_names) / sizeof(k_phase_names[0]) == PH_COUNT, "one name per phase");
 extern "C" int32_t shz_table_phase_stats(shz_table* t, double* seconds, uint32_t cap, uint32_t* n, int32_t reset) {
   if (!t) return SHZ_E_INVALID;

@@ -34,6 +34,45 @@ int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out) {
   return SHZ_OK;
 }
 
+hipError_t shz_block_alloc(shz_ctx* ctx, uint64_t bytes, void** out, uint64_t* got) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  {
+    std::lock_guard<std::mutex> lk(ctx->blocks_mu);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->blocks.size(); ++i) {
+      const uint64_t c = ctx->blocks[i].cap;
+      if (c >= bytes && c <= bytes + bytes / 2 && (best < 0 || c < ctx->blocks[best].cap)) best = i;
+    }
+    if (best >= 0) {
+      *out = ctx->blocks[best].p;
+      if (got) *got = ctx->blocks[best].cap;
+      ctx->blocks.erase(ctx->blocks.begin() + best);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {   // short of memory: what the cache holds goes back first
+    (void)hipGetLastError();
+    std::vector<shz_buf> drop;
+    {
+      std::lock_guard<std::mutex> lk(ctx->blocks_mu);
+      drop.swap(ctx->blocks);
+    }
+    for (shz_buf& b : drop) (void)hipFree(b.p);
+    e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess && got) *got = bytes;
+  return e;
+}
+
+void shz_block_free(shz_ctx* ctx, void* p, uint64_t bytes) {
+  if (!p) return;
+  if (bytes < (256ull << 20)) { (void)hipFree(p); return; }   // small blocks are cheap either way
+  std::lock_guard<std::mutex> lk(ctx->blocks_mu);
+  ctx->blocks.push_back(shz_buf{p, bytes});
+}
+
 int32_t shz_mailbox(shz_ctx* ctx, uint64_t bytes, void** out) {
   if (ctx->mail_cap < bytes) {
     if (ctx->mail) {
@@ -164,6 +203,9 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& b : ctx->ws)
     if (b.p) (void)hipFree(b.p);
+  for (auto& b : ctx->blocks)
+    if (b.p) (void)hipFree(b.p);
+  ctx->blocks.clear();
   if (ctx->d_window) (void)hipFree(ctx->d_window);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
@@ -274,6 +316,14 @@ extern "C" int32_t shz_release_workspace(shz_ctx* ctx, uint64_t* freed_bytes) {
       b.p = nullptr;
       b.cap = 0;
     }
+  {
+    std::lock_guard<std::mutex> lk(ctx->blocks_mu);
+    for (shz_buf& b : ctx->blocks) {
+      (void)hipFree(b.p);
+      freed += b.cap;
+    }
+    ctx->blocks.clear();
+  }
   if (freed_bytes) *freed_bytes = freed;
   return SHZ_OK;
 }

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -112,6 +113,10 @@ struct shz_ctx {
   hipEvent_t ev_twin = nullptr;
   void* mail = nullptr;         // shz_mailbox
   uint64_t mail_cap = 0;
+  // large device blocks (table slabs, run arenas, staging columns) that a destroyed table handed back: kept for the next
+  // table instead of going through hipFree + hipMalloc (shz_block_alloc / shz_block_free; shz_release_workspace drops them)
+  std::vector<shz_buf> blocks;
+  std::mutex blocks_mu;
 };
 
 // Copy on ctx->stream.  Host <-> device copies of 16 KB .. 64 MB go through pinned bounce buffers owned by the context
@@ -125,6 +130,13 @@ hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
 // pinned host memory owned by the ctx for small latency-critical transfers (counts, result blocks, query uploads):
 // grows to the largest request; contents are the caller's between two calls
 int32_t shz_mailbox(shz_ctx* ctx, uint64_t bytes, void** out);
+
+// Big blocks with reuse.  A hipFree'd gigabyte comes back from the driver scrubbed at ~40 GB/s on its next use (measured:
+// the same 207 GB reservation took 0 s on untouched memory and 5 s after 70 GB had been freed in the process), so blocks
+// a table gives up stay with the context.  alloc: the smallest cached block of bytes <= size <= 1.5 x bytes, else
+// hipMalloc (cached blocks are dropped first if the device is short); *got = the block's real size.  Thread-safe.
+hipError_t shz_block_alloc(shz_ctx* ctx, uint64_t bytes, void** out, uint64_t* got);
+void shz_block_free(shz_ctx* ctx, void* p, uint64_t bytes);
 
 // ensure ws slot has >= bytes (grow-only; contents not preserved)
 int32_t shz_ws_reserve(shz_ctx* ctx, int slot, uint64_t bytes, void** out);

@@ -53,7 +53,8 @@ struct shz_table {
   char* slab = nullptr;                                 // ONE allocation the segments' columns are carved from
   uint64_t slab_bytes = 0, slab_used = 0;
   uint64_t* rbuf = nullptr;                             // run arena
-  uint64_t rcap = 0;                                    // ... rows it holds
+  uint64_t rcap = 0, rbuf_bytes = 0;                    // ... rows it holds, size of the block
+  uint64_t st_bytes[3] = {0, 0, 0};                     // sizes of the reserved staging blocks
   std::vector<shz_run> runs;
   int run_sb = 0, run_ob = 0;                           // packing of the runs (0: none yet)
   bool stage_reserved = false;                          // the staging columns were sized by shz_table_reserve: kept
@@ -63,7 +64,7 @@ struct shz_table {
 // phases of the single-GPU build, in the order shz_table_phase_stats reports them
 enum { PH_STAGE_ALLOC = 0, PH_INSERT, PH_DEDUP_FROZEN, PH_TOPUP, PH_MAXES, PH_SORT, PH_MERGE, PH_UNIQ, PH_COL_ALLOC, PH_COMPACT,
        PH_BUCKET, PH_SLICE, PH_STAGE_FREE, PH_RUN_PACK, PH_RUN_SORT, PH_RUN_UNIQ, PH_KW_PLAN, PH_KW_MERGE, PH_RESERVE_WAIT,
-       PH_COUNT };
+       PH_RESERVE_ALLOC /* helper thread's hipMalloc seconds: beside the build, not part of it */, PH_COUNT };
 static_assert(PH_COUNT <= SHZ_TABLE_PHASES, "phase table too small");
 static inline double now_s() {
   timespec ts;
