@@ -248,6 +248,15 @@ int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const
                         const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
                         uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
                         uint32_t* out_nres, uint32_t* out_nhash, uint64_t* out_npairs);
+/* Test switches that force the vote tiles' rare paths (never set in production): SHZ_DEBUG_VT_TINY_HEAVY gives the list
+ * of ranges handed from vt_stream to vt_fold room for ONE range; SHZ_DEBUG_VT_PROBE1 lets an LDS hash probe give up
+ * after one round (what a full table would cause).  Either way the pass's flag word is set, and the sub-batch is voted
+ * again through the full sort (align_matches' result is a function of the votes, recognizer.py:289-338: same arrays).
+ * shz_match_vt_redo: how many sub-batches went that way since the context was created. */
+#define SHZ_DEBUG_VT_TINY_HEAVY 1u
+#define SHZ_DEBUG_VT_PROBE1 2u
+int32_t shz_set_debug(shz_ctx* ctx, uint32_t flags);
+int32_t shz_match_vt_redo(shz_ctx* ctx, uint64_t* count);
 /* rows streamed / pairs voted by the last shz_match_batch (for HBM accounting) */
 int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, uint64_t* distinct_keys);
 

@@ -74,6 +74,8 @@ SIGNATURES = {
     "shz_match_batch": (C.c_int32, [vp, vp, vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     vp, vp, vp, vp, vp, vp, vp]),
     "shz_match_stats": (C.c_int32, [vp, u64p, u64p, u64p]),
+    "shz_set_debug": (C.c_int32, [vp, C.c_uint32]),
+    "shz_match_vt_redo": (C.c_int32, [vp, u64p]),
     "shz_comm_unique_id": (C.c_int32, [vp]),
     "shz_comm_create": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "shz_comm_destroy": (C.c_int32, [vp]),
@@ -199,6 +201,15 @@ class Context:
         hbm, cus, clk = C.c_uint64(), C.c_int32(), C.c_int32()
         self.check(lib().shz_device_info(self.h, name, 256, C.byref(hbm), C.byref(cus), C.byref(clk)))
         return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cus.value, "clock_khz": clk.value}
+
+    def set_debug(self, flags: int):
+        """SHZ_DEBUG_* test switches (1: tiny hand-over list, 2: LDS probes give up after one round)."""
+        self.check(lib().shz_set_debug(self.h, int(flags)))
+
+    def vt_redo_count(self) -> int:
+        n = C.c_uint64()
+        self.check(lib().shz_match_vt_redo(self.h, C.byref(n)))
+        return n.value
 
     def mem_info(self):
         """(free, total) bytes of device memory right now."""

@@ -99,6 +99,8 @@ struct shz_ctx {
   std::vector<struct shz_prof_rec> prof_free;
   // match stats
   uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
+  uint64_t st_vt_redo = 0;      // sub-batches whose vote tiles flagged an overflow and were voted again by the full sort
+  uint32_t debug = 0;           // SHZ_DEBUG_* (shz_set_debug): switches that force rare paths, for tests
   // extraction stats: cells fp32 peak picking left undecided, of those decided on fp64 values, frames recomputed for
   // that, passes repeated with fp64 staging
   uint64_t st_und = 0, st_und_f64 = 0, st_und_ffts = 0, st_fallbacks = 0;

@@ -924,6 +924,7 @@ __global__ __launch_bounds__(256) void m_topn_final_kernel(const uint64_t* __res
 #define VT_MAXQ SHZ_SEG_MAX     // queries per vote pass (their votes stay apart as segments of the sort: shz_sort_u32_seg)
 #define VT_MAXTOPN 8
 #define VT_MAX_DBITS 12
+#define VT_MAX_DSPLIT 8        // delta bits above those a sweep may split by (vt_fold_kernel): tracks of up to 2^20 frames
 #define VT_EMPTY 0xFFFFFFFFu
 #ifndef VT_ORDERED_BITS
 #define VT_ORDERED_BITS 16     // upper bits of a vote the radix passes order (two passes of 8)
@@ -979,10 +980,14 @@ __device__ __forceinline__ uint32_t vt_hash(uint32_t x) { return (x * 2654435761
 
 // Slots of N (song | delta) keys in table 1 and of their N songs in table 2, open addressing, inserted if absent.
 // All compare-and-swaps of a round are in flight together: a round costs one LDS round trip, not 2 N.
+// A probe sequence is BOUNDED by `probe_limit` rounds (the table size: after that many steps every slot has been seen; a
+// debug switch lowers it).  The fill limits of the callers keep a free slot within reach, so the bound is never met -- but
+// if a table ever is full (a caller's limit broken, a zero-trip clear: the hang of round 2) the lanes give up, *err is
+// set, the pass's results are void and the host repeats the pass through the full sort.
 template <int N, int B1, int B2>
 __device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const uint32_t (&x1)[N], const uint32_t (&x2)[N],
                                          const bool (&valid)[N], uint32_t (&s1)[N], uint32_t (&s2)[N], bool (&fresh1)[N],
-                                         bool (&fresh2)[N]) {
+                                         bool (&fresh2)[N], uint32_t probe_limit, uint32_t* __restrict__ err) {
   bool p1[N], p2[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) {
@@ -991,11 +996,12 @@ __device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const u
     p1[r] = p2[r] = valid[r];
     fresh1[r] = fresh2[r] = false;
   }
-  for (;;) {
+  for (uint32_t round = 0;; ++round) {
     bool any = false;
 #pragma unroll
     for (int r = 0; r < N; ++r) any |= p1[r] | p2[r];
     if (!any) break;
+    if (round >= probe_limit) { atomicOr(err, 1u); break; }   // (the slots of the lanes that gave up are valid indices of the wrong entries)
     uint32_t o1[N], o2[N];
 #pragma unroll
     for (int r = 0; r < N; ++r) {
@@ -1025,12 +1031,13 @@ __device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const u
 template <int N>
 __device__ __forceinline__ void vt_votes(uint32_t* key1, uint32_t* cnt, uint32_t* key2, unsigned long long* best,
                                          uint32_t* ded, uint16_t* lst, uint32_t* n1, uint32_t* n2, bool count1,
-                                         const uint32_t (&v)[N], const bool (&valid)[N], int dbits, uint32_t dmask) {
+                                         const uint32_t (&v)[N], const bool (&valid)[N], int dbits, uint32_t dmask,
+                                         uint32_t probe_limit, uint32_t* __restrict__ err) {
   uint32_t x1[N], x2[N], s1[N], s2[N];
   bool f1[N], f2[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) { x1[r] = v[r] >> 1; x2[r] = x1[r] >> dbits; }
-  vt_slots<N, 13, 12>(key1, key2, x1, x2, valid, s1, s2, f1, f2);
+  vt_slots<N, 13, 12>(key1, key2, x1, x2, valid, s1, s2, f1, f2, probe_limit, err);
   uint32_t c[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) c[r] = valid[r] ? atomicAdd(&cnt[s1[r]], 1u) : 0u;
@@ -1085,7 +1092,8 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
                                                              const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ n_ranges, uint32_t cap, vt_plan pl,
                                                              uint32_t topn, uint64_t* __restrict__ c_pack,
-                                                             uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup) {
+                                                             uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
+                                                             uint32_t probe_limit, uint32_t* __restrict__ err) {
   __shared__ uint4 t1[VT_SLOTS / 2];                  // table 1: key1[VT_SLOTS] | cnt[VT_SLOTS]
   __shared__ uint32_t key2[VT_SLOTS2];
   __shared__ unsigned long long best[VT_SLOTS2];     // count << 32 | dmask - delta
@@ -1100,6 +1108,11 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
   if (blockIdx.x >= nt) return;   // the usual case: nothing was handed over
   const uint32_t dmask = (1u << pl.dbits) - 1u, smask = (pl.sb >= 32 ? ~0u : (1u << pl.sb) - 1u);
   const int slb = pl.g_lo - 1 - pl.dbits;           // song-id bits below the ordered ones: what sweeps may split by
+  // ... and behind them the delta bits above the low VT_MAX_DBITS: one song of a long track (> 2^12 frames) may vote for
+  // more distinct deltas than table 1 holds; its delta range is then swept in parts.  The song's entry of table 2 lives
+  // through all parts of its deltas (counts of one (song, delta) pair are complete inside one part, so the maximum over
+  // the parts is the maximum over all deltas; ties keep the smallest delta; the flagged votes add up).
+  const int dsb = pl.dbits > VT_MAX_DBITS ? pl.dbits - VT_MAX_DBITS : 0;
   auto clear1 = [&]() {
     for (uint32_t i = j; i < VT_SLOTS / 4; i += VT_THREADS) t1[i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
     for (uint32_t i = VT_SLOTS / 4 + j; i < VT_SLOTS / 2; i += VT_THREADS) t1[i] = make_uint4(0, 0, 0, 0);
@@ -1118,18 +1131,22 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
     uint32_t na = 0, nb = 0;                         // (both 0 behind the last tile: nothing is loaded)
     if (gn < nt) { na = ranges[gn].x; nb = ranges[gn].y; }
     const bool checked = b - a > VT_LIMIT2;         // fewer votes than either table may hold: no sweep can overflow
-    int cl = 0, nsl = 0;                             // candidate list in use, log2 of the number of sweeps
+    int cl = 0, ns = 0, nd = 0;                      // candidate list in use; song bits / delta bits the sweeps split by
     bool prefetched = false;
     for (bool done = (a >= b); !done;) {             // until a sweep count is found under which every sweep fits
       bool over = false;
+      uint32_t over_songs = 0;                         // songs in table 2 when a sweep overflowed
       cl = 0;
+      const int nsl = ns + nd;
       for (uint32_t sw = 0; sw < (1u << nsl) && !over; ++sw) {
+        const uint32_t song_part = sw >> nd, delta_part = sw & ((1u << nd) - 1u);
+        const bool last_of_song = delta_part == (1u << nd) - 1u;
         // ---- A
         if (!checked && nsl == 0 && b - a <= VT_ROWS * VT_THREADS) {   // the usual tile: its rows are in registers
           bool ok[VT_ROWS];
 #pragma unroll
           for (int r = 0; r < VT_ROWS; ++r) ok[r] = a + r * VT_THREADS + j < b;
-          vt_votes<VT_ROWS>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, false, pre, ok, pl.dbits, dmask);
+          vt_votes<VT_ROWS>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, false, pre, ok, pl.dbits, dmask, probe_limit, err);
         } else {
           for (uint32_t row = 0, base = a; base < b; base += VT_THREADS, ++row) {
             const uint32_t i = base + j;
@@ -1137,11 +1154,13 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
             if (row < VT_ROWS && nsl == 0) v[0] = row == 0 ? pre[0] : row == 1 ? pre[1] : pre[2];
             else if (i < b) v[0] = k[i];
             const uint32_t x = v[0] >> 1;
-            const bool ok[1] = {i < b && (nsl == 0 || (((x >> pl.dbits) & ((1u << slb) - 1u)) >> (slb - nsl)) == sw)};
-            vt_votes<1>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, true, v, ok, pl.dbits, dmask);
+            const bool ok[1] = {i < b && (ns == 0 || (((x >> pl.dbits) & ((1u << slb) - 1u)) >> (slb - ns)) == song_part) &&
+                                (nd == 0 || ((x & dmask) >> (pl.dbits - nd)) == delta_part)};
+            vt_votes<1>(key1, cnt, key2, best, ded, lst, &s_n1, &s_n2, true, v, ok, pl.dbits, dmask, probe_limit, err);
             if (checked) {
               __syncthreads();
               over = s_n1 > VT_LIMIT || s_n2 > VT_LIMIT2;      // uniform: read between two barriers
+              over_songs = s_n2;
               __syncthreads();
               if (over) break;
             }
@@ -1156,7 +1175,7 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
           for (int r = 0; r < VT_ROWS; ++r) { const uint32_t i = na + r * VT_THREADS + j; pre[r] = i < nb ? k[i] : 0u; }
         }
         // ---- C: rank = (count descending, song id ascending); the smallest delta reaching the count is in best
-        if (j < 64 && !over) {
+        if (j < 64 && !over && last_of_song) {
           constexpr int CE = 12;                     // songs per lane whose rank stays in registers (n2 <= 768: the usual tile)
           uint64_t cpk[CE];
           const bool cached = n2 <= 64 * CE;         // uniform
@@ -1169,7 +1188,7 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
               cpk[u] = cs[u] == 0xFFFFFFFFu ? 0ull : ((best[cs[u]] >> 32) << 32) | (0xFFFFFFFFu - (key2[cs[u]] & smask));
           }
           uint64_t prev = ~0ull;
-          const uint64_t old = (sw > 0 && lane < topn) ? s_cpack[cl][lane] : 0ull;
+          const uint64_t old = (song_part > 0 && lane < topn) ? s_cpack[cl][lane] : 0ull;
           for (uint32_t n = 0; n < topn; ++n) {
             uint64_t m = old < prev ? old : 0ull;
             uint32_t ms = 0xFFFFFFFFu;               // slot of m (0xFFFFFFFF: the old candidate), index of the entry if cached
@@ -1200,16 +1219,30 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
         __syncthreads();
         // ---- D (also what an overflowing sweep leaves behind)
         clear1();
-        for (uint32_t e = j; e < n2; e += VT_THREADS) { const uint32_t s = lst[e]; key2[s] = VT_EMPTY; best[s] = 0; ded[s] = 0; }
-        if (j == 0) { s_n1 = 0; s_n2 = 0; }
-        if (!over) cl ^= 1;
+        if (last_of_song || over) {                  // table 2 lives through the parts of a song's delta range
+          for (uint32_t e = j; e < n2; e += VT_THREADS) { const uint32_t s = lst[e]; key2[s] = VT_EMPTY; best[s] = 0; ded[s] = 0; }
+          if (j == 0) s_n2 = 0;
+        }
+        if (j == 0) s_n1 = 0;
+        if (!over && last_of_song) cl ^= 1;
         __syncthreads();
       }
       if (!over) { done = true; break; }
-      // at nsl == slb a sweep is one song of the last group (<= 2^VT_MAX_DBITS deltas) + less than VT_TILE other votes,
-      // which fits; the host does not choose this path for wider deltas.  (The test only keeps a wrong call from hanging.)
-      if (nsl >= slb) { if (j < VT_MAXTOPN) s_cpack[0][j] = 0; cl = 0; done = true; }
-      ++nsl;
+      // at nsl == slb + dsb a sweep is 2^VT_MAX_DBITS deltas of one song of the last group + less than VT_TILE other
+      // votes, which fits.  Should it not (a broken invariant), the range is given up and the pass flagged: the host
+      // repeats it through the full sort.
+      if (nsl >= slb + dsb) {
+        if (j < VT_MAXTOPN) s_cpack[0][j] = 0;
+        if (j == 0) atomicOr(err, 2u);
+        cl = 0;
+        done = true;
+      }
+      // split by song ids while many songs share the sweep; a sweep of a handful of songs that still overflows holds one
+      // long track's deltas: split those (a query against a stationary 10-minute track would otherwise walk through
+      // every song-id level, each a full pass over the range, before the first delta split)
+      if (ns < slb && (over_songs > 8 || nd >= dsb)) ++ns;
+      else if (nd < dsb) ++nd;
+      else ++ns;
       __syncthreads();
     }
     if (!prefetched) {   // an empty tile, or one given up
@@ -1251,9 +1284,11 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
                                                        vt_plan pl, uint32_t topn, uint64_t* __restrict__ c_pack,
                                                        uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
                                                        uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
-                                                       uint32_t* __restrict__ heavy_q, uint32_t heavy_cap) {
+                                                       uint32_t* __restrict__ heavy_q, uint32_t heavy_cap,
+                                                       uint32_t probe_limit, uint32_t* __restrict__ err) {
   constexpr int VW_S2 = 1 << VW_B2;
   constexpr uint32_t VW_LIMIT2 = VW_S2 - 68;        // + one row of new songs stays below VW_S2
+  static_assert(VW_LIMIT2 + 64 < (uint32_t)VW_S2 && VW_LIMIT1 + 64 < VW_S1, "a probe must find a free slot in either table");
   __shared__ uint4 t1[VW_S1 / 2];                    // key1[VW_S1] | cnt[VW_S1]
   __shared__ uint4 t2[VW_S2];                        // key2[VW_S2] | ded[VW_S2] | best[VW_S2] (8 bytes each)
   uint32_t* const key1 = (uint32_t*)t1;
@@ -1286,7 +1321,7 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
       uint32_t s1[1], s2[1];
       bool f1[1], f2[1];
       const bool ok[1] = {act};
-      vt_slots<1, VW_B1, VW_B2>(key1, key2, x1, x2, ok, s1, s2, f1, f2);
+      vt_slots<1, VW_B1, VW_B2>(key1, key2, x1, x2, ok, s1, s2, f1, f2, probe_limit, err);
       if (act) {
         const uint32_t c = atomicAdd(&cnt[s1[0]], 1u);
         atomicMax(&best[s2[0]], ((unsigned long long)(c + 1u) << 32) | (dmask - (x1[0] & dmask)));
@@ -1334,6 +1369,7 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
       if (lane == 0) {
         const uint32_t idx = atomicAdd(n_heavy, 1u);
         if (idx < heavy_cap) { heavy[idx] = make_uint2(batch_start, e); heavy_q[idx] = vt_query_of_tile(pl, g); }
+        else atomicOr(err, 4u);                      // no room in the list: the range's votes would be lost -> the pass is repeated
       }
     };
     uint32_t r0, r1, r2, r3;                         // the next four rows of votes: loads in flight
@@ -1607,7 +1643,10 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   (void)h0;
   uint32_t q0 = 0;
   uint32_t step = std::min<uint32_t>(n_queries, MAX_Q_SUB);
+  bool redo_full_sort = false;   // the vote tiles of this sub-batch flagged an overflow: once more, through the full sort
+  const uint32_t vt_probe_limit_1 = (ctx->debug & SHZ_DEBUG_VT_PROBE1) ? 1u : 0u;   // debug: a probe gives up after one round
   while (q0 < n_queries) {
+    const uint32_t flags_sub = flags | (redo_full_sort ? SHZ_MATCH_FULL_SORT : 0u);
     uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     // the vote budget: sized from what a hash yielded in the last sub-batch, so that the head (compose, sort, probe: a
     // round trip) is not run on 200 queries, then 100, then 50 to find that 25 fit
@@ -1706,13 +1745,14 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     // results and per-query counters in ONE device block: one fill before, one copy after.
     // layout: npairs[nq] u64 | sid, delta, aligned, dedup [nq * topn] u32 each | nres[nq] | nhash[nq]
     const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
-    const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8;
+    const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8 + 8;   // + the vote tiles' flag word (and a pad)
     void* rb;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
     SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));
     uint64_t* d_np = (uint64_t*)rb;
     uint32_t* r_sid = (uint32_t*)(d_np + nq);
     uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
+    uint32_t* d_vt_err = d_nh + nq;   // set by a vote-tile kernel whose LDS table or range list overflowed: the sub-batch is voted again by the full sort
     if (nq > 1) {   // one query: its counts are the totals
       hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
                          (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
@@ -1757,9 +1797,6 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       continue;
     }
     if (P >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "query %u alone produces %llu matches (limit 2^32)", q0, (unsigned long long)P);
-    ctx->st_rows += rows_total;
-    ctx->st_pairs += P;
-    ctx->st_keys += ng;
     std::vector<uint64_t> h_votes(nq, P);   // votes per query (read back with the counts)
     if (nq > 1) memcpy(h_votes.data(), (const char*)mailp + 256, (uint64_t)nq * 8);
     void* tile_x = nullptr;
@@ -1786,10 +1823,10 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       std::vector<vpass> passes;
       const int qbits32 = 31 - mb.sb - mb.dbits;
       static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
-      bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0 && !(flags & SHZ_MATCH_FULL_SORT);
+      bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0 && !(flags_sub & SHZ_MATCH_FULL_SORT);
       // vote tiles (vt_fold_kernel): two radix passes + an LDS fold per tile instead of four passes + the record chain
       static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
-      const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS;
+      const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS + VT_MAX_DSPLIT;
       if (use32) {
         const uint32_t q_per_pass = tiles ? (uint32_t)VT_MAXQ : (1u << std::min(qbits32, 30));   // tiles: no query bits in the vote
         uint64_t v = 0;
@@ -1807,8 +1844,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       // ONE query with few votes (a 5-10 s query against thousands of songs): expand, then one workgroup folds the
       // unordered votes (vt_fold_kernel over the single range [0, P)) -- 5 launches instead of the 9 of sort + fold,
       // and the launches are what such a match costs
-      const bool one_wg = !use32 && !(flags & SHZ_MATCH_FULL_SORT) && nq == 1 && P <= VT_ONE_WG_MAX && qbits32 >= 0 && tiles_env != 0 && topn <= VT_MAXTOPN &&
-                          mb.dbits <= VT_MAX_DBITS;
+      const bool one_wg = !use32 && !(flags_sub & SHZ_MATCH_FULL_SORT) && nq == 1 && P <= VT_ONE_WG_MAX && qbits32 >= 0 && tiles_env != 0 && topn <= VT_MAXTOPN &&
+                          mb.dbits <= VT_MAX_DBITS + VT_MAX_DSPLIT;
       uint64_t pmax = 0;
       for (const vpass& vp : passes) pmax = std::max(pmax, vp.v_hi - vp.v_lo);
       void *v0, *v1;   // E lives in one of SORT_A/B; the vote buffers use SORT_C/D
@@ -1870,7 +1907,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
           uint32_t* heavy_q = n_heavy + 4;
           hipLaunchKernelGGL(vt_one_range_kernel, dim3(1), dim3(1), 0, ctx->stream, n_heavy, heavy, heavy_q, (uint32_t)pp);
           hipLaunchKernelGGL(vt_fold_kernel, dim3(1), dim3(VT_THREADS), 0, ctx->stream, (const uint32_t*)k32, (const uint2*)heavy,
-                             (const uint32_t*)n_heavy, 1u, pl, topn, (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd);
+                             (const uint32_t*)n_heavy, 1u, pl, topn, (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd,
+                             vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VT_SLOTS, d_vt_err);
           hipLaunchKernelGGL(vt_rank_kernel, dim3(1), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
                              (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, 1u,
                              rs, rdl, ra, rd, r_n + vp.qa);
@@ -1904,7 +1942,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
               pl.tb[i + 1] = pl.tb[nqp];
               sp.bq[i + 1] = sp.bq[nqp];
             }
-            const uint32_t nt = pl.tb[nqp], hcap = nt * VW_HEAVY_PER_TILE;
+            const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
             int sel = 0;
             SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax, pp, pl.g_lo, Bt, sp, &sel));
             const uint32_t* ks = sel ? k32 + pmax : k32;
@@ -1925,14 +1963,16 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
             const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(t->max_sid, 1u));
             if ((double)(1u << slb_) + 64.0 / per_song <= 40.0)
               hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
+                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
             else
               hipLaunchKernelGGL(vt_stream_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap);
+                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
             hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
                                dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
                                (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
-                               (uint32_t*)cdd + (uint64_t)nt * topn);
+                               (uint32_t*)cdd + (uint64_t)nt * topn, vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VT_SLOTS, d_vt_err);
             hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
                                (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, hcap,
                                rs, rdl, ra, rd, r_n + vp.qa);
@@ -1962,6 +2002,15 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       const uint64_t* h_np = (const uint64_t*)hb;
       const uint32_t* h_sid = (const uint32_t*)(h_np + nq);
       const uint32_t *h_delta = h_sid + nres, *h_al = h_delta + nres, *h_dd = h_al + nres, *h_n = h_dd + nres, *h_nh = h_n + nq;
+      if (h_nh[nq] != 0 && !redo_full_sort) {   // a vote tile overflowed (its results are void): the same queries again, full sort
+        ++ctx->st_vt_redo;
+        redo_full_sort = true;
+        continue;
+      }
+      redo_full_sort = false;
+      ctx->st_rows += rows_total;
+      ctx->st_pairs += P;
+      ctx->st_keys += ng;
       if (nq == 1) {
         if (out_npairs) out_npairs[q0] = P;
         if (out_nhash) out_nhash[q0] = (uint32_t)mu;
@@ -2013,6 +2062,17 @@ extern "C" int32_t shz_match_pairs(shz_ctx* ctx, shz_table* t, const uint32_t* k
                      out_nhash, out_npairs, &sink));
   *count = sink.count;
   if (sink.count > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_match_pairs: %llu votes, capacity %llu", (unsigned long long)sink.count, (unsigned long long)cap);
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_set_debug(shz_ctx* ctx, uint32_t flags) {
+  if (!ctx) return SHZ_E_INVALID;
+  ctx->debug = flags;
+  return SHZ_OK;
+}
+extern "C" int32_t shz_match_vt_redo(shz_ctx* ctx, uint64_t* count) {
+  if (!ctx || !count) return SHZ_E_INVALID;
+  *count = ctx->st_vt_redo;
   return SHZ_OK;
 }
 
