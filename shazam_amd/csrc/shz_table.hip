@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void m_topn_final_kernel(const uint64_t* __res
 // count << 32 | ~delta, atomicAdd of the flags) and picks the tile's top-n; a last kernel ranks the tiles' candidates
 // of every query.  g_pack (count << 32 | ~sid) is the rank of align_matches as in m_reduce_kernel: count descending,
 // song id ascending, and the delta of a record is the smallest one reaching the count (recognizer.py:305-322 as
-// restated in oracle/match.py).
+// restated in oracle/cpu_ref.py: vote / align_matches).
 #define VT_THREADS 1024
 #define VT_SLOTS 8192          // per LDS table (4 arrays of 4 bytes x VT_SLOTS = 128 KB)
 #define VT_TILE 2048           // votes per tile before the cut is moved to the next group border

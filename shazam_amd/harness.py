@@ -77,6 +77,18 @@ def write_reports(rows, csv_name: str):
     from sklearn.metrics import accuracy_score, classification_report, confusion_matrix
     y_true = [r["file_name_played"] for r in rows]
     y_pred = [r["file_name_result"] for r in rows]
+    # CM_: the reference's own table (recognizer_test.py:491-499): played names on both axes with the play counts on the
+    # diagonal; every miss sets its diagonal cell to 0 and puts a 1 in the column of the name that came back (a column
+    # that appears on demand when that name was never played)
+    names = sorted(set(y_true))
+    cm = pd.DataFrame(0, index=pd.Index(names, name="Actual"), columns=pd.Index(names, name="Actual"), dtype=object)
+    for n in y_true:
+        cm.at[n, n] += 1
+    for t, p_ in zip(y_true, y_pred):
+        if t != p_:
+            cm.at[t, t] = 0
+            cm.at[t, p_] = 1
+    cm.to_csv("CM_" + csv_name)
     pd.DataFrame(confusion_matrix(y_true, y_pred)).to_csv("CMSK_" + csv_name)
     pd.DataFrame(classification_report(y_true, y_pred, output_dict=True, zero_division=0)).transpose().to_csv("CRSK_" + csv_name)
     pd.DataFrame([accuracy_score(y_true, y_pred)]).to_csv("ASSK_" + csv_name)
