@@ -170,107 +170,167 @@ template <typename T>
 __device__ __forceinline__ T stage_value(double p) {
   return ((__double2hiint(p) | __double2loint(p)) != 0) ? (T)p : (T)1.0;
 }
+// fp32 staging tests the CONVERTED value (one 32-bit compare): a power so small that it rounds to 0.0f (< 1e-45, -450 dB)
+// is staged as 1.0 like an exact zero.  Either way the cell is below 0 dB: it cannot be a peak for amp_min >= 0 (negative
+// amp_min takes the fp64 pass), and it cannot outrank a cell that can.
+template <>
+__device__ __forceinline__ float stage_value<float>(double p) {
+  const float f = (float)p;
+  return f == 0.0f ? 1.0f : f;
+}
 
 // One frame: windowed samples v[8] (complex point j + 256 t = samples 2n, 2n+1) -> power of the 2049 bins.
 // `before_out()` runs between the last butterflies and the outputs (the persistent kernel issues the next frame's
 // loads there); `out(k, p)` receives every bin k once with its scaled power p (>= 0; stage_value maps it).
-// Ends with a barrier: buf may be rewritten on return.
+// On return buf may be rewritten (the barrier that says so sits right behind the last LDS reads).
+//
+// The passes are those of the Stockham formulation (pass p: inputs [j + 256 t], twiddles W_{8 Ns}^{k t}, outputs
+// [(j div Ns) 8 Ns + k + Ns r]) -- same operations on the same values in the same order, so every bit of the output
+// is what it was -- but the ARRAYS BETWEEN THE PASSES LIVE IN PLACE: a butterfly writes its eight results into the eight
+// LDS slots it read its inputs from.  Nobody else reads or writes those slots during the pass, so the barrier "everybody
+// has read" between a pass's reads and its writes is gone; and with the butterflies of passes 2 and 3 numbered so that a
+// wave's pass-3 inputs are exactly the slots that wave wrote in pass 2, the barrier between those two passes is gone as
+// well (the LDS executes one wave's instructions in order).  Three workgroup barriers per frame instead of seven.
+//   slot of A1[i] (after pass 1) = i;   slot of A2[i] = i[2:0] | i[10:6] << 3 | i[5:3] << 8;
+//   slot of A3[i] = i[2:0] | i[10:9] << 3 | i[8:6] << 5 | i[5:3] << 8          (i[a:b] = bits a..b of i)
+// Bank swizzle SZ: among 16 neighbouring lanes the slots vary in bits {3,4,5,6} (pass 1 stores), {0,1,2,5} (pass 2),
+// {0,1,2,8} (passes 3 and 4); XOR-ing bit 4 -> 1, bit 5 -> 3 and 0, bit 6 -> 2, bit 8 -> 3 makes each of those sets hit 16
+// different 16-byte bank groups.
+__device__ __forceinline__ int stft_sz(int s) {
+  return s ^ (((s >> 4) & 1) << 1) ^ (((s >> 5) & 1) * 9) ^ (((s >> 6) & 1) << 2) ^ (((s >> 8) & 1) << 3);
+}
+// ---- the pieces of a frame (stft_frame = one frame; stft_psd2_kernel interleaves the pieces of two) ----
+struct stft_tabs { const cplx *tw, *tw2, *tw3; };
+__device__ __forceinline__ stft_tabs stft_tabs_at(const cplx* tw) { return stft_tabs{tw, tw + TW_MAIN, tw + TW_MAIN + TW_P2}; }
+
+// pass 1: Ns = 1 (no twiddles); A1[8j + r] at slot 8j + r
+__device__ __forceinline__ void stft_p1(cplx (&v)[8], cplx* buf, int j) {
+  dft8f(v);
+  const int a = stft_sz(8 * j);   // the low three bits hold swizzle terms only
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[a ^ r] = v[r];
+}
+// pass 2: Ns = 8, twiddles W_64^(k t) from the table.  Butterfly j2 = L[2:0] | W << 3 | L[5:3] << 5 (a wave takes the
+// butterflies whose bits 3,4 spell its number): inputs A1[j2 + 256 t] at slots j2 + 256 t, results written back there.
+__device__ __forceinline__ void stft_p2_load(cplx (&v)[8], const cplx* buf, int j) {
+  const int W = j >> 6, L = j & 63;
+  const int j2 = (L & 7) | (W << 3) | ((L >> 3) << 5);
+  const int a0 = stft_sz(j2), a1 = stft_sz(j2 | 256);   // t even / odd (slot bit 8 enters the swizzle)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = buf[((t & 1) ? a1 : a0) + (t >> 1) * 512];
+}
+__device__ __forceinline__ void stft_p2_rest(cplx (&v)[8], cplx* buf, const stft_tabs& T, int j) {
+  const int W = j >> 6, L = j & 63;
+  const int j2 = (L & 7) | (W << 3) | ((L >> 3) << 5);
+  const int a0 = stft_sz(j2), a1 = stft_sz(j2 | 256);
+  const int k = L & 7;
+#pragma unroll
+  for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw2[(t - 1) * 8 + k]);
+  dft8f(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[((r & 1) ? a1 : a0) + (r >> 1) * 512] = v[r];
+}
+// pass 3: Ns = 64, twiddles W_512^(k t).  Butterfly j: inputs A2[j + 256 t] at slots j[2:0] | W << 3 | t << 5 | j[5:3] << 8
+// -- all written by this wave in pass 2: no barrier in front.  Slot bits 5 and 6 (t & 1, t & 2) enter the swizzle, bit 7
+// (t & 4) is a plain offset of 128 elements.
+__device__ __forceinline__ void stft_p3_load(cplx (&v)[8], const cplx* buf, int j) {
+  const int b3 = stft_sz((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
+  const int q0 = b3, q1 = (b3 ^ 9) + 32, q2 = (b3 ^ 4) + 64, q3 = (b3 ^ 13) + 96;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = buf[((t & 3) == 0 ? q0 : (t & 3) == 1 ? q1 : (t & 3) == 2 ? q2 : q3) + (t >> 2) * 128];
+}
+__device__ __forceinline__ void stft_p3_rest(cplx (&v)[8], cplx* buf, const stft_tabs& T, int j) {
+  const int b3 = stft_sz((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
+  const int q0 = b3, q1 = (b3 ^ 9) + 32, q2 = (b3 ^ 4) + 64, q3 = (b3 ^ 13) + 96;
+  const int k = j & 63;
+#pragma unroll
+  for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw3[(t - 1) * 64 + k]);
+  dft8f(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[((r & 3) == 0 ? q0 : (r & 3) == 1 ? q1 : (r & 3) == 2 ? q2 : q3) + (r >> 2) * 128] = v[r];
+}
+// pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
+// W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
+// Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
+// thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
+// b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
+// Inputs: A3[b + 512 c] at slot b[2:0] | c << 3 | b[8:6] << 5 | b[5:3] << 8 (c = 1 sets slot bit 3, c = 2 bit 4, which
+// flips swizzle bit 1); v[0..3] = butterfly j, v[4..7] = butterfly 512 - j (thread 0: 256).
+__device__ __forceinline__ void stft_p4_load(cplx (&v)[8], const cplx* buf, int j) {
+  const int bb = j == 0 ? 256 : 512 - j;
+  auto slot4 = [](int b) { return stft_sz((b & 7) | (((b >> 6) & 7) << 5) | (((b >> 3) & 7) << 8)); };
+  const int sa = slot4(j), sb = slot4(bb);
+  v[0] = buf[sa]; v[1] = buf[sa ^ 8]; v[2] = buf[sa ^ 18]; v[3] = buf[sa ^ 26];
+  v[4] = buf[sb]; v[5] = buf[sb ^ 8]; v[6] = buf[sb ^ 18]; v[7] = buf[sb ^ 26];
+}
+// Twiddles: butterfly 512 - j uses W^(1024 - 2j) and its powers, mirrors of butterfly j's (tw_mirror): W1' = -i conj(W1),
+// W2' = -conj(W2), W3' = i conj(W3); the post-pass needs W^j, W^(512-j) and their mirrors W^(1024-j), W^(512+j).
+// Thread 0's second butterfly is b = 256, not 512: its twiddles are constants, selected below.
+// SPECIAL = false: the caller knows that no lane of the wave is thread 0 (waves 1-3): the selects fold away.
+template <bool SPECIAL, class PRE, class OUT>
+__device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, int j, double scale, PRE&& before_out, OUT&& out) {
+  const cplx* tw = T.tw;
+  const bool t0 = SPECIAL && j == 0;
+  const int bb = t0 ? 256 : 512 - j;
+  cplx A0 = v[0], A1 = v[1], A2 = v[2], A3 = v[3], B0 = v[4], B1 = v[5], B2 = v[6], B3 = v[7];
+  const double h = 0.70710678118654752440;
+  {
+    const cplx w1 = tw[2 * j];
+    const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+    // b = 256: W^512 = (h, -h), W^1024 = (0, -1), W^1536 = (-h, -h)
+    const cplx v1 = csel(t0, make_double2(h, -h), tw_mirror(w1));
+    const cplx v2 = csel(t0, make_double2(0.0, -1.0), make_double2(-w2.x, w2.y));
+    const cplx v3 = csel(t0, make_double2(-h, -h), make_double2(w3.y, w3.x));
+    A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
+    dft4(A0, A1, A2, A3);
+    B1 = cmul(B1, v1); B2 = cmul(B2, v2); B3 = cmul(B3, v3);
+    dft4(B0, B1, B2, B3);
+  }
+  before_out();
+  const double scale2 = scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
+  // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024], wk = W^k
+  auto pair_out = [&](int k, cplx wk, cplx zk, cplx zm) {
+    const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
+    const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
+    const cplx wo = cmul(wk, o);
+    const cplx xa = cadd(e, wo), xb = csub(e, wo);
+    const double sc = (k != 0) ? scale2 : scale;  // bin 2048 pairs with k = 0: both unscaled
+    const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
+    const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
+    out(k, pa);
+    if (k != 1024) out(2048 - k, pb);
+  };
+  // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
+  // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
+  const cplx wj = tw[j], wa = tw[bb];                                  // W^j, W^(512-j)   [thread 0: W^0, W^256]
+  const cplx wma = tw_mirror(wa);                                      // W^(512+j)        [thread 0: W^768]
+  const cplx w3rd = csel(t0, make_double2(h, -h), wma);                // k = j + 512      [thread 0: W^512]
+  const cplx w4th = csel(t0, wma, tw_mirror(wj));                      // k = 1024 - j     [thread 0: W^768]
+  pair_out(bb, wa, B0, csel(t0, B3, A3));   // ordered so that each pair frees its operands early
+  pair_out(j, wj, A0, csel(t0, A0, B3));
+  pair_out(j + 512, w3rd, A1, csel(t0, A3, B2));
+  pair_out(t0 ? 768 : 1024 - j, w4th, B1, csel(t0, B2, A2));
+  if (t0) pair_out(1024, make_double2(0.0, -1.0), A2, A2);
+}
+
 template <class PRE, class OUT>
 __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, double scale, PRE&& before_out, OUT&& out) {
   cplx* buf = lds;
-  const cplx* tw = lds + 2048;
-  const cplx* tw2 = tw + TW_MAIN;
-  const cplx* tw3 = tw2 + TW_P2;
-  const int sw = (j >> 3) & 7;  // swizzle term of element j + 256 t
-  // pass 1: Ns = 1 (no twiddles); element 8j + r lives at (8j + r) ^ (j & 7)
-  dft8f(v);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) buf[(8 * j + r) ^ (j & 7)] = v[r];
+  const stft_tabs T = stft_tabs_at(lds + 2048);
+  stft_p1(v, buf, j);
   __syncthreads();
-
-  // pass 2: Ns = 8, twiddles W_64^(k t) from the table (seven 16-byte reads instead of two reads and five complex products)
-  {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
-    __syncthreads();
-    const int k = j & 7;
-#pragma unroll
-    for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw2[(t - 1) * 8 + k]);
-    dft8f(v);
-    const int base = ((j >> 3) << 6) + k;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) buf[(base + 8 * r) ^ r] = v[r];  // ((base + 8r) >> 3) & 7 == r
-    __syncthreads();
-  }
-  // pass 3: Ns = 64, twiddles W_512^(k t)
-  {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = buf[(j + 256 * t) ^ sw];
-    __syncthreads();
-    const int k = j & 63;
-#pragma unroll
-    for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw3[(t - 1) * 64 + k]);
-    dft8f(v);
-    const int base = ((j >> 6) << 9) + k;
-    const int ks = (k >> 3) & 7;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) buf[(base + 64 * r) ^ ks] = v[r];
-    __syncthreads();
-  }
-  // pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
-  // W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
-  // Z[2048 - k]: X[k] = E + W^k O, X[2048-k] = conj(E - W^k O).  2048 - (b + 512 c) = (512 - b) + 512 (3 - c), so a
-  // thread that computes the butterflies b = j and 512 - j holds both members of its four pairs (thread 0: b = 0 and
-  // b = 256, which pair with themselves) -- 32 KB of LDS stores, the reads behind them and two barriers less per frame.
-  // Twiddles: butterfly 512 - j uses W^(1024 - 2j) and its powers, mirrors of butterfly j's (tw_mirror): W1' = -i conj(W1),
-  // W2' = -conj(W2), W3' = i conj(W3); the post-pass needs W^j, W^(512-j) and their mirrors W^(1024-j), W^(512+j).
-  // Thread 0's second butterfly is b = 256, not 512: its twiddles are constants, selected below.
-  {
-    const bool t0 = j == 0;
-    const int bb = t0 ? 256 : 512 - j;
-    const int swb = (bb >> 3) & 7;
-    cplx A0 = buf[j ^ sw], A1 = buf[(j + 512) ^ sw], A2 = buf[(j + 1024) ^ sw], A3 = buf[(j + 1536) ^ sw];
-    cplx B0 = buf[bb ^ swb], B1 = buf[(bb + 512) ^ swb], B2 = buf[(bb + 1024) ^ swb], B3 = buf[(bb + 1536) ^ swb];
-    const double h = 0.70710678118654752440;
-    {
-      const cplx w1 = tw[2 * j];
-      const cplx w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-      // b = 256: W^512 = (h, -h), W^1024 = (0, -1), W^1536 = (-h, -h)
-      const cplx v1 = csel(t0, make_double2(h, -h), tw_mirror(w1));
-      const cplx v2 = csel(t0, make_double2(0.0, -1.0), make_double2(-w2.x, w2.y));
-      const cplx v3 = csel(t0, make_double2(-h, -h), make_double2(w3.y, w3.x));
-      A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
-      dft4(A0, A1, A2, A3);
-      B1 = cmul(B1, v1); B2 = cmul(B2, v2); B3 = cmul(B3, v3);
-      dft4(B0, B1, B2, B3);
-    }
-    before_out();
-    const double scale2 = scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
-    // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024], wk = W^k
-    auto pair_out = [&](int k, cplx wk, cplx zk, cplx zm) {
-      const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
-      const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
-      const cplx wo = cmul(wk, o);
-      const cplx xa = cadd(e, wo), xb = csub(e, wo);
-      const double sc = (k != 0) ? scale2 : scale;  // bin 2048 pairs with k = 0: both unscaled
-      const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
-      const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
-      out(k, pa);
-      if (k != 1024) out(2048 - k, pb);
-    };
-    // thread j >= 1: (j, 2048 - j), (j + 512, 1536 - j), (512 - j, 1536 + j), (1024 - j, 1024 + j);
-    // thread 0 (butterflies 0 and 256): (0, 2048), (512, 1536), (256, 1792), (768, 1280) and bin 1024 alone
-    const cplx wj = tw[j], wa = tw[bb];                                  // W^j, W^(512-j)   [thread 0: W^0, W^256]
-    const cplx wma = tw_mirror(wa);                                      // W^(512+j)        [thread 0: W^768]
-    const cplx w3rd = csel(t0, make_double2(h, -h), wma);                // k = j + 512      [thread 0: W^512]
-    const cplx w4th = csel(t0, wma, tw_mirror(wj));                      // k = 1024 - j     [thread 0: W^768]
-    pair_out(bb, wa, B0, csel(t0, B3, A3));   // ordered so that each pair frees its operands early
-    pair_out(j, wj, A0, csel(t0, A0, B3));
-    pair_out(j + 512, w3rd, A1, csel(t0, A3, B2));
-    pair_out(t0 ? 768 : 1024 - j, w4th, B1, csel(t0, B2, A2));
-    if (t0) pair_out(1024, make_double2(0.0, -1.0), A2, A2);
-  }
-  __syncthreads();  // buf is rewritten by the next frame's pass 1
+  stft_p2_load(v, buf, j);
+  stft_p2_rest(v, buf, T, j);
+  // (no barrier: the slots this wave reads next are the ones it has just written)
+  stft_p3_load(v, buf, j);
+  stft_p3_rest(v, buf, T, j);
+  __syncthreads();
+  stft_p4_load(v, buf, j);
+  __syncthreads();  // everybody holds its inputs: buf may be rewritten by the next frame's pass 1
+  // thread 0's butterflies pair differently: the selects that say so cost 36 instructions per frame
+  // (running the select-free variant in waves 1-3 behind a wave-uniform branch was tried: the split basic blocks cost
+  // 76 spilled registers against 16)
+  stft_p4_rest<true>(v, T, j, scale, before_out, out);
 }
 
 #define P32_STRIDE 2064  // floats per fp32 row: 2049 bins padded so every row starts 64-byte aligned

@@ -652,7 +652,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uin
   seg_of_block(sp, blockIdx.x, seg, lo, len, hb, nbs);
   // a segment starts wherever its query's votes start: up to three keys in front of the first 16-byte boundary and
   // behind the last one are counted singly, the rest four per load
-  const uint32_t head = min((4u - (lo & 3u)) & 3u, len), nv = (len - head) >> 2, tail0 = head + 4u * nv;
+  // (alignment by ADDRESS: the key buffer itself may start anywhere, e.g. the second half of a ping-pong pair)
+  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(keys + lo) >> 2) & 3u);
+  const uint32_t head = min((4u - mis) & 3u, len), nv = (len - head) >> 2, tail0 = head + 4u * nv;
   {
     const uint4* k4 = (const uint4*)(keys + lo + head);
     uint4 x[SORT_ROUNDS / 4];
@@ -826,11 +828,12 @@ extern "C" int32_t shz_sort_keys32_seg(shz_ctx* ctx, const uint32_t* keys, const
   }
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void* k0;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  const uint64_t n4 = (n + 3) & ~3ull;   // the second buffer of the ping-pong pair starts 16-byte aligned
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, (n4 + n) * 4, &k0));
   SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
   int sel = 0;
-  SHZ_TRY(shz_sort_u32_seg(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, n, (int)bit_lo, (int)bit_hi, sp, &sel));
-  SHZ_HIP(ctx, shz_memcpy(ctx, out, (uint32_t*)k0 + (sel ? n : 0), n * 4, hipMemcpyDeviceToHost));
+  SHZ_TRY(shz_sort_u32_seg(ctx, (uint32_t*)k0, (uint32_t*)k0 + n4, n, (int)bit_lo, (int)bit_hi, sp, &sel));
+  SHZ_HIP(ctx, shz_memcpy(ctx, out, (uint32_t*)k0 + (sel ? n4 : 0), n * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;
 }
@@ -843,10 +846,11 @@ extern "C" int32_t shz_sort_keys32(shz_ctx* ctx, const uint32_t* keys, uint64_t 
   if (bit_hi > 32 || bit_lo > bit_hi) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_sort_keys32: bits [%u, %u)", bit_lo, bit_hi);
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   void *k0, *o;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, n * 8, &k0));
+  const uint64_t n4 = (n + 3) & ~3ull;   // the second buffer of the ping-pong pair starts 16-byte aligned
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, (n4 + n) * 4, &k0));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, n * 8, &o));
   SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
-  SHZ_TRY(shz_sort_u32_widen(ctx, (uint32_t*)k0, (uint32_t*)k0 + n, (uint64_t*)o, n, (int)bit_lo, (int)bit_hi, add, nullptr));
+  SHZ_TRY(shz_sort_u32_widen(ctx, (uint32_t*)k0, (uint32_t*)k0 + n4, (uint64_t*)o, n, (int)bit_lo, (int)bit_hi, add, nullptr));
   SHZ_HIP(ctx, shz_memcpy(ctx, out64, o, n * 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;

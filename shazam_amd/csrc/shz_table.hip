@@ -1849,7 +1849,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       uint64_t pmax = 0;
       for (const vpass& vp : passes) pmax = std::max(pmax, vp.v_hi - vp.v_lo);
       void *v0, *v1;   // E lives in one of SORT_A/B; the vote buffers use SORT_C/D
-      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, pmax * 8, &v0));
+      const uint64_t pmax4 = (pmax + 3) & ~3ull;   // second 4-byte vote buffer of a pass: 16-byte aligned behind the first
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, pmax * 8 + 16, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, pmax * 8, &v1));
       // the sub-group of every expand tile's first pair, for all passes in one launch: pass table (votes, first entry)
       // up, one kernel
@@ -1944,8 +1945,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
             }
             const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
             int sel = 0;
-            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax, pp, pl.g_lo, Bt, sp, &sel));
-            const uint32_t* ks = sel ? k32 + pmax : k32;
+            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax4, pp, pl.g_lo, Bt, sp, &sel));
+            const uint32_t* ks = sel ? k32 + pmax4 : k32;
             // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
             void *ts, *cp, *cd, *cdd;
             const uint64_t ncand = ((uint64_t)nt + hcap) * topn;
@@ -1978,7 +1979,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                                rs, rdl, ra, rd, r_n + vp.qa);
             SHZ_HIP(ctx, hipGetLastError());
           } else {
-            SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax, (uint64_t*)v1, pp, 1, B, 0, nullptr));
+            SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax4, (uint64_t*)v1, pp, 1, B, 0, nullptr));
             SHZ_TRY(vote_fold(ctx, (const uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
           }
         } else {
