@@ -446,6 +446,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--queries", type=int, default=2000)
     ap.add_argument("--match-songs", type=int, default=1000000, help="tracks of the match_1M extra (0 = skip)")
+    ap.add_argument("--ws-limit-mb", type=float, default=0.0, help="cap on the extraction workspace (shz_set_workspace_limit): "
+                    "smaller sub-batches, e.g. so that one sub-batch's staged spectrogram stays in the 256 MB Infinity Cache (experiment)")
     ap.add_argument("--scaling-songs", type=int, default=100000, help="fixed corpus of the db_build_scaling extra: the same "
                     "at every --gpus N (0 = skip)")
     a = ap.parse_args()
@@ -478,6 +480,8 @@ def main():
     from shazam_amd import _ffi
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", local)))
     info = ctx.device_info()
+    if a.ws_limit_mb > 0:
+        ctx.set_workspace_limit(int(a.ws_limit_mb * 1e6))
     nc = a.clips
     frames_per_clip = int(_ffi.lib().shz_frame_count(n_samples))
     pcm = ctx.synth_pcm(1234, rank * nc, nc, n_samples, 0, 8000)        # resident in HBM before timing
@@ -559,6 +563,8 @@ def main():
                       "hashes_per_step_per_gpu": int(n_hashes), "parallelism": f"dp{world} (one process per GPU)",
                       "device": info["name"], "compute_units": info["compute_units"]},
            "x_realtime_per_gpu": value / world, "roofline": roofline}
+    if a.ws_limit_mb > 0:
+        out["config"]["workspace_limit_mb"] = a.ws_limit_mb
 
     # ---- extras (outside the timed region) -------------------------------------------------
     if cpu is not None:
