@@ -169,13 +169,15 @@ int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
 /* Staging precision of shz_peaks / shz_fingerprint_batch.  Default (0): the power spectrogram is staged in fp32 and
  * the cells fp32 cannot decide (shared window maxima, threshold within 1e-7) are re-derived in fp64; results are
  * those of the fp64 path bit for bit.  1: stage fp64 and decide everything in the peak kernel (twice the HBM traffic;
- * what a pass falls back to on stationary / plateau material, and always used for amp_min < 0).
+ * what a clip falls back to on stationary / plateau material, and always used for amp_min < 0).
  * Env SHZ_STAGE_F64=1 forces it process-wide. */
 int32_t shz_set_stage_f64(shz_ctx* ctx, int32_t enabled);
 /* Counters since ctx creation: cells left undecided by the fp32 pass, those that needed fp64 values, FFT frames
- * recomputed for them, passes repeated with fp64 staging. Any pointer may be NULL. */
+ * recomputed for them, whole passes repeated with fp64 staging, single clips re-run with fp64 staging (windows with more
+ * tied cells than the verification kernel takes: only those clips are redone and spliced into the batch) and the frames
+ * of those clips.  Any pointer may be NULL. */
 int32_t shz_extract_stats(shz_ctx* ctx, uint64_t* undecided, uint64_t* decided_f64, uint64_t* frames_recomputed,
-                          uint64_t* f64_passes);
+                          uint64_t* f64_passes, uint64_t* f64_clips, uint64_t* f64_clip_frames);
 
 /* sha1(f"{f1}|{f2}|{dt}")[:10 bytes] per key (__init__.py:207-208; BINARY(10) at
  * mysql_database.py:48).  key32: host or device (SHZ_IN_DEVICE); out10: host [n][10]. */

@@ -53,7 +53,7 @@ SIGNATURES = {
     "shz_fingerprint_batch": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32,
                                           vp, vp, u64p, C.c_uint64, u64p]),
     "shz_set_stage_f64": (C.c_int32, [vp, C.c_int32]),
-    "shz_extract_stats": (C.c_int32, [vp, u64p, u64p, u64p, u64p]),
+    "shz_extract_stats": (C.c_int32, [vp, u64p, u64p, u64p, u64p, u64p, u64p]),
     "shz_sha1_prefix": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "shz_sha1_invert": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "shz_table_create": (C.c_int32, [vp, C.POINTER(vp)]),
@@ -328,9 +328,10 @@ class Context:
         self.check(lib().shz_set_stage_f64(self.h, 1 if enabled else 0))
 
     def extract_stats(self) -> dict:
-        v = [C.c_uint64() for _ in range(4)]
+        v = [C.c_uint64() for _ in range(6)]
         self.check(lib().shz_extract_stats(self.h, *[C.byref(x) for x in v]))
-        return dict(zip(("undecided", "decided_f64", "frames_recomputed", "f64_passes"), (int(x.value) for x in v)))
+        return dict(zip(("undecided", "decided_f64", "frames_recomputed", "f64_passes", "f64_clips", "f64_clip_frames"),
+                        (int(x.value) for x in v)))
 
     def stft_db(self, pcm, clip_off, fs=44100, pcm_device=False, power=False):
         co, nc = self._clip_off(clip_off)

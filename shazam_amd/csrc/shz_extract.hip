@@ -1274,6 +1274,7 @@ struct pass_tail {
   void *o_a = nullptr, *o_b = nullptr;     // device arrays the entries were written to
   uint32_t n_clips = 0;
   bool out_dev = false, want_hashes = true, stay = false;
+  const uint32_t* d_fb = nullptr;          // device bitmap of the clips flagged XF_FALLBACK_CLIP
 };
 
 // Queue one pass on ctx->stream, up to and including the asynchronous copies of its read-back.  `stay`: the entries stay
@@ -1312,11 +1313,14 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   // whatever way this pass ends, the second stream is idle afterwards (workspace slots may be re-allocated by the next call)
   struct s2_guard { shz_ctx* c; bool on; ~s2_guard() { if (on && c->stream2) (void)hipStreamSynchronize(c->stream2); } } s2g{ctx, overlap};
   void *p_ctl, *p_offs;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, sizeof(xctl) + 64, &p_ctl));
+  const uint64_t fb_words = ((uint64_t)n_clips + 31) / 32;   // bitmap of clips that need fp64 staging, behind the control block
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, 256 + fb_words * 4 + 64, &p_ctl));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
   xctl* d_ctl = (xctl*)p_ctl;
   unsigned long long* d_offs = (unsigned long long*)p_offs;
-  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, sizeof(xctl), ctx->stream));   // (offs[0] = 0 is written by xctl_offsets_kernel)
+  static_assert(sizeof(xctl) <= 256, "the clip bitmap starts 256 bytes behind the control block");
+  uint32_t* d_fb = (uint32_t*)((char*)p_ctl + 256);
+  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, 256 + fb_words * 4, ctx->stream));   // (offs[0] = 0 is written by xctl_offsets_kernel)
   // where the entries go: the caller's device arrays, or staging arrays that are copied out after the final sync
   void *o_a = want_hashes ? (void*)key32 : (void*)peak_f, *o_b = want_hashes ? (void*)t1 : (void*)peak_t;
   uint64_t o_cap = cap;
@@ -1444,6 +1448,8 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         va.p_lo = p_lo;
         va.p_hi = p_hi;
         va.amp_min = amp_min;
+        va.fb_clips = d_fb;
+        va.clip0 = sb.c0;
         hipLaunchKernelGGL(peak_verify_kernel, dim3((unsigned)ctx->prop.multiProcessorCount), dim3(256), 0,
                            ctx->stream, va);
         SHZ_HIP(ctx, hipGetLastError());
@@ -1539,6 +1545,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   pt->out_dev = out_dev;
   pt->want_hashes = want_hashes;
   pt->stay = stay;
+  pt->d_fb = d_fb;
   SHZ_HIP(ctx, hipMemcpyAsync(pt->mp, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
   SHZ_HIP(ctx, hipMemcpyAsync(pt->mp + pt->off_offs, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (pt->spec) {
@@ -1557,7 +1564,7 @@ static int32_t extract_finish(shz_ctx* ctx, const pass_tail& pt, uint16_t* peak_
   memcpy(hctl, pt.mp, sizeof(xctl));
   if (offs_out) memcpy(offs_out, pt.mp + pt.off_offs, (uint64_t)(pt.n_clips + 1) * 8);
   const uint64_t total = pt.want_hashes ? hctl->hash_base : hctl->peak_base;
-  const bool clean = !(hctl->flags & (XF_FALLBACK | XF_PEAK_CAP));
+  const bool clean = !(hctl->flags & (XF_FALLBACK | XF_PEAK_CAP));   // (XF_FALLBACK_CLIP: the other clips' entries stand)
   if (clean && !pt.out_dev && !pt.stay && total <= cap && total <= pt.o_cap && total) {
     void* ha = pt.want_hashes ? (void*)key32 : (void*)peak_f;
     void* hb = pt.want_hashes ? (void*)t1 : (void*)peak_t;
@@ -1576,11 +1583,105 @@ static int32_t extract_finish(shz_ctx* ctx, const pass_tail& pt, uint16_t* peak_
 static int32_t extract_pass(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
                             double amp_min, uint32_t fan, uint32_t flags, bool want_hashes, const xparams& xp,
                             uint16_t* peak_f, uint32_t* peak_t, uint32_t* key32, uint32_t* t1, uint64_t* offs_out,
-                            uint64_t cap, xctl* hctl) {
+                            uint64_t cap, xctl* hctl, std::vector<uint32_t>* flagged_clips = nullptr) {
   pass_tail pt;
   SHZ_TRY(extract_enqueue(ctx, pcm, clip_off, n_clips, fs, amp_min, fan, flags, want_hashes, xp, peak_f, peak_t, key32, t1,
                           cap, false, &pt));
-  return extract_finish(ctx, pt, peak_f, peak_t, key32, t1, offs_out, cap, hctl);
+  SHZ_TRY(extract_finish(ctx, pt, peak_f, peak_t, key32, t1, offs_out, cap, hctl));
+  if (flagged_clips) {
+    flagged_clips->clear();
+    if (hctl->flags & XF_FALLBACK_CLIP) {   // which clips: the bitmap behind the control block (a second, small read-back; rare)
+      std::vector<uint32_t> bm(((uint64_t)n_clips + 31) / 32);
+      SHZ_HIP(ctx, shz_memcpy(ctx, bm.data(), pt.d_fb, bm.size() * 4, hipMemcpyDeviceToHost));
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (uint32_t c = 0; c < n_clips; ++c)
+        if ((bm[c >> 5] >> (c & 31)) & 1u) flagged_clips->push_back(c);
+    }
+  }
+  return SHZ_OK;
+}
+
+static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips, uint32_t fs,
+                              double amp_min, uint32_t fan, uint32_t flags, bool want_hashes, uint16_t* peak_f, uint32_t* peak_t,
+                              uint64_t* peak_off, uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count);
+
+// The clips fp32 staging could not settle (windows with more than PV_MAX_NEAR tied cells: a click per hop, a full-scale
+// plateau) are fingerprinted again ONE BY ONE with fp64 staging, and their entries replace what the fp32 pass left for
+// them -- the other 999 clips of a batch keep the entries they have.  A (2 or 4 bytes per entry) and B are the output
+// arrays (device or host), offs the n_clips + 1 offsets of the fp32 pass; *total is updated.
+static int32_t splice_f64_clips(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t fs, double amp_min,
+                                uint32_t fan, uint32_t flags, bool want_hashes, const std::vector<uint32_t>& flagged, void* A,
+                                void* B, uint64_t* offs, uint32_t n_clips, uint64_t cap, uint64_t* total) {
+  const bool out_dev = (flags & SHZ_OUT_DEVICE) != 0;
+  const uint64_t b_a = want_hashes ? 4 : 2;
+  const bool saved = ctx->stage_f64;
+  struct restore { shz_ctx* c; bool v; ~restore() { c->stage_f64 = v; } } rs{ctx, saved};
+  struct redo { uint64_t cnt = 0; std::vector<uint32_t> b, a32; std::vector<uint16_t> a16; };
+  std::vector<redo> R(flagged.size());
+  // 1) every flagged clip once more, fp64 staging, entries to the host
+  uint64_t new_total = *total;
+  for (size_t fi = 0; fi < flagged.size(); ++fi) {
+    const uint32_t c = flagged[fi];
+    redo& r = R[fi];
+    const uint64_t frames_c = shz_frame_count(clip_off[c + 1] - clip_off[c]);
+    uint64_t cap_c = frames_c * 64 * (want_hashes ? (fan > 1 ? fan - 1 : 1) : 1) + 4096;
+    uint64_t o2[2] = {0, 0};
+    for (int attempt = 0;; ++attempt) {
+      r.b.resize(cap_c);
+      if (want_hashes) r.a32.resize(cap_c); else r.a16.resize(cap_c);
+      ctx->stage_f64 = true;
+      const int32_t rc = extract_driver(ctx, pcm, clip_off + c, 1, fs, amp_min, fan, flags & ~SHZ_OUT_DEVICE, want_hashes,
+                                        want_hashes ? nullptr : r.a16.data(), want_hashes ? nullptr : r.b.data(),
+                                        want_hashes ? nullptr : o2, want_hashes ? r.a32.data() : nullptr,
+                                        want_hashes ? r.b.data() : nullptr, want_hashes ? o2 : nullptr, cap_c, &r.cnt);
+      ctx->stage_f64 = saved;
+      if (rc == SHZ_E_CAPACITY && attempt == 0) { cap_c = r.cnt + 64; continue; }
+      SHZ_TRY(rc);
+      break;
+    }
+    ++ctx->st_f64_clips;
+    ctx->st_f64_frames += frames_c;
+    new_total = new_total - (offs[c + 1] - offs[c]) + r.cnt;
+  }
+  // 2) room for the result?  (*total = what the caller has to provide)
+  if (new_total > cap) {
+    *total = new_total;
+    SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)new_total, (unsigned long long)cap);
+  }
+  // 3) splice, from the back: the offsets in front of a clip stay what they are
+  for (size_t fi = flagged.size(); fi-- > 0;) {
+    const uint32_t c = flagged[fi];
+    const redo& r = R[fi];
+    const uint64_t cnt = r.cnt, old0 = offs[c], old1 = offs[c + 1], tail = *total - old1;
+    const void* src_a = want_hashes ? (const void*)r.a32.data() : (const void*)r.a16.data();
+    if (out_dev) {
+      if (cnt != old1 - old0 && tail) {   // the entries behind the clip move: through scratch (the ranges overlap)
+        void* tmp;
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, tail * 4, &tmp));
+        SHZ_HIP(ctx, hipMemcpyAsync(tmp, (char*)A + old1 * b_a, tail * b_a, hipMemcpyDeviceToDevice, ctx->stream));
+        SHZ_HIP(ctx, hipMemcpyAsync((char*)A + (old0 + cnt) * b_a, tmp, tail * b_a, hipMemcpyDeviceToDevice, ctx->stream));
+        SHZ_HIP(ctx, hipMemcpyAsync(tmp, (char*)B + old1 * 4, tail * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        SHZ_HIP(ctx, hipMemcpyAsync((char*)B + (old0 + cnt) * 4, tmp, tail * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      if (cnt) {
+        SHZ_HIP(ctx, shz_memcpy(ctx, (char*)A + old0 * b_a, src_a, cnt * b_a, hipMemcpyHostToDevice));
+        SHZ_HIP(ctx, shz_memcpy(ctx, (char*)B + old0 * 4, r.b.data(), cnt * 4, hipMemcpyHostToDevice));
+      }
+      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      if (cnt != old1 - old0 && tail) {
+        memmove((char*)A + (old0 + cnt) * b_a, (char*)A + old1 * b_a, tail * b_a);
+        memmove((char*)B + (old0 + cnt) * 4, (char*)B + old1 * 4, tail * 4);
+      }
+      if (cnt) {
+        memcpy((char*)A + old0 * b_a, src_a, cnt * b_a);
+        memcpy((char*)B + old0 * 4, r.b.data(), cnt * 4);
+      }
+    }
+    for (uint32_t i = c + 1; i <= n_clips; ++i) offs[i] = offs[i] - (old1 - old0) + cnt;
+    *total = *total - (old1 - old0) + cnt;
+  }
+  return SHZ_OK;
 }
 
 // shared driver for shz_peaks / shz_fingerprint_batch
@@ -1655,7 +1756,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     ctx->st_und_f64 += ha.und_f64 + hb.und_f64;
     ctx->st_und_ffts += ha.und_ffts + hb.und_ffts;
     const uint64_t na = want_hashes ? ha.hash_base : ha.peak_base, nb = want_hashes ? hb.hash_base : hb.peak_base;
-    const bool clean = !((ha.flags | hb.flags) & (XF_FALLBACK | XF_PEAK_CAP)) && nb <= tb.o_cap &&
+    const bool clean = !((ha.flags | hb.flags) & (XF_FALLBACK | XF_PEAK_CAP | XF_FALLBACK_CLIP)) && nb <= tb.o_cap &&
                        ((flags & SHZ_OUT_DEVICE) || na <= ta.o_cap || na > cap);
     if (clean) {   // (anything else -- fp64 fallback, a list too small -- is sorted out by the single pass below)
       if (offs)
@@ -1674,14 +1775,22 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
       return SHZ_OK;
     }
   }
+  std::vector<uint64_t> offs_own;   // the per-clip fallback needs the offsets whether the caller wants them or not
+  if (!offs) { offs_own.assign((size_t)n_clips + 1, 0); offs = offs_own.data(); }
+  std::vector<uint32_t> flagged;
   for (int attempt = 0;; ++attempt) {
+    static const bool xtrace = getenv("SHZ_TRACE_EXTRACT") != nullptr;
+    if (xtrace) fprintf(stderr, "extract: pass attempt %d clips %u f32 %d\n", attempt, n_clips, (int)xp.f32);
     SHZ_TRY(extract_pass(ctx, pcm, clip_off, n_clips, fs, amp_min, fan, flags, want_hashes, xp, peak_f, peak_t, key32, t1,
-                         offs, cap, &h));
+                         offs, cap, &h, &flagged));
+    if (xtrace) fprintf(stderr, "extract: pass done flags %u flagged %zu und %llu\n", h.flags, flagged.size(), (unsigned long long)h.und_total);
     ctx->st_und += h.und_total;
     ctx->st_und_f64 += h.und_f64;
     ctx->st_und_ffts += h.und_ffts;
-    const uint64_t total = want_hashes ? h.hash_base : h.peak_base;
+    uint64_t total = want_hashes ? h.hash_base : h.peak_base;
     bool again = false;
+    // many clips flagged: one fp64 pass over everything is cheaper than a pass per clip
+    if (xp.f32 && !flagged.empty() && flagged.size() > std::max<size_t>(8, n_clips / 16)) h.flags |= XF_FALLBACK;
     if (xp.f32 && (h.flags & XF_FALLBACK)) {  // stationary / plateau material: decide on fp64 values
       xp.f32 = false;
       ++ctx->st_fallbacks;
@@ -1709,6 +1818,13 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     if (count) *count = total;
     if (total > cap) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)total,
                               (unsigned long long)cap);
+    if (xp.f32 && !flagged.empty()) {
+      const int32_t rc = splice_f64_clips(ctx, pcm, clip_off, fs, amp_min, fan, flags, want_hashes, flagged,
+                                          want_hashes ? (void*)key32 : (void*)peak_f, want_hashes ? (void*)t1 : (void*)peak_t, offs,
+                                          n_clips, cap, &total);
+      if (count) *count = total;   // (on SHZ_E_CAPACITY: what the caller has to provide)
+      SHZ_TRY(rc);
+    }
     return SHZ_OK;
   }
 }
@@ -1720,12 +1836,14 @@ extern "C" int32_t shz_set_stage_f64(shz_ctx* ctx, int32_t enabled) {
 }
 
 extern "C" int32_t shz_extract_stats(shz_ctx* ctx, uint64_t* undecided, uint64_t* decided_f64, uint64_t* frames_recomputed,
-                                     uint64_t* f64_passes) {
+                                     uint64_t* f64_passes, uint64_t* f64_clips, uint64_t* f64_clip_frames) {
   if (!ctx) return SHZ_E_INVALID;
   if (undecided) *undecided = ctx->st_und;
   if (decided_f64) *decided_f64 = ctx->st_und_f64;
   if (frames_recomputed) *frames_recomputed = ctx->st_und_ffts;
   if (f64_passes) *f64_passes = ctx->st_fallbacks;
+  if (f64_clips) *f64_clips = ctx->st_f64_clips;
+  if (f64_clip_frames) *f64_clip_frames = ctx->st_f64_frames;
   return SHZ_OK;
 }
 

@@ -104,6 +104,7 @@ struct shz_ctx {
   // extraction stats: cells fp32 peak picking left undecided, of those decided on fp64 values, frames recomputed for
   // that, passes repeated with fp64 staging
   uint64_t st_und = 0, st_und_f64 = 0, st_und_ffts = 0, st_fallbacks = 0;
+  uint64_t st_f64_clips = 0, st_f64_frames = 0;   // clips re-run one by one with fp64 staging (per-clip fallback), their frames
   bool stage_f64 = false;       // shz_set_stage_f64: stage fp64 power and decide ties in peak_pick (no fp32 pass)
   // pinned bounce buffers of shz_memcpy (two halves, an event each)
   void* pin[2] = {nullptr, nullptr};
