@@ -30,9 +30,20 @@ SEED_TRACKS, SEED_NOISE = 4321, 777
 
 ROWS_PER_FRAME_HINT = 18.5   # hashes per frame of the synthetic corpora (17.6-18.7 measured): sizes shz_table_reserve
 
+# Corpora: "tonal" = six sinusoids + white noise per track, white query noise (rounds 1-2); "music" = music-like tracks (four
+# voices of decaying harmonic notes, percussive onsets) under traffic-like low-passed query noise (oracle/synth.music_clip /
+# traffic_noise; what the reference's accuracy was measured on is real music under street noise, recognizer_test.py:39-40)
+MUSIC_AMP, MUSIC_BED, MUSIC_BURST, TRAFFIC_AMP = 3000, 100, 1500, 2000
+
+
+def synth_tracks(ctx, corpus, c0, nc, n_samples, tone_amp, noise_amp, out, start=0):
+    if corpus == "music":
+        return ctx.synth_corpus(1, SEED_TRACKS, c0, nc, n_samples, MUSIC_AMP, MUSIC_BED, MUSIC_BURST, start, out=out)
+    return ctx.synth_pcm(SEED_TRACKS, c0, nc, n_samples, tone_amp, noise_amp, start, out=out)
+
 
 def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1500, finalize_every=0, shards=1,
-                progress=None, reserve=True):
+                progress=None, reserve=True, corpus="tonal"):
     """Synthesise `songs` tracks on the device, fingerprint them in chunks and build one HBM table.
     Every `finalize_every` songs the staged rows are sealed into a sorted run (bounded staging and sort scratch; rows become
     visible at the final finalize).  Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
@@ -55,7 +66,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     t_build0 = time.perf_counter()
     for c0 in range(0, songs, chunk):
         nc = min(chunk, songs - c0)
-        ctx.synth_pcm(SEED_TRACKS, c0, nc, n_samples, tone_amp, noise_amp, out=pcm)
+        synth_tracks(ctx, corpus, c0, nc, n_samples, tone_amp, noise_amp, pcm)
         off = np.arange(nc + 1, dtype=np.uint64) * n_samples
         ctx.sync()
         t0 = time.perf_counter()
@@ -87,22 +98,29 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     return tbl, stats, (kbuf, tbuf, cap)
 
 
-def make_queries(ctx, tids, starts, qn, snr, tone_amp=4000, noise_amp=1500, noise_clip0=0):
+def make_queries(ctx, tids, starts, qn, snr, tone_amp=4000, noise_amp=1500, noise_clip0=0, corpus="tonal"):
     """Device PCM of len(tids) queries: crop [start, start+qn) of track tid, mixed with an independent noise stream at
     `snr` dB by the reference's rule (snr >= 200: clean).  Returns (DevBuf, buffers to free)."""
     from shazam_amd import _ffi
     nb = len(tids)
     sig, noi = ctx.alloc(nb * qn * 2), ctx.alloc(nb * qn * 2)
     for i in range(nb):
-        ctx.check(_ffi.lib().shz_synth_pcm(ctx.h, SEED_TRACKS, int(tids[i]), 1, qn, tone_amp, noise_amp, int(starts[i]),
-                                           _ffi.vp(sig.ptr + i * qn * 2)))
-    ctx.synth_pcm(SEED_NOISE, noise_clip0, nb, qn, 0, 8000, out=noi)
+        if corpus == "music":
+            ctx.check(_ffi.lib().shz_synth_corpus(ctx.h, 1, SEED_TRACKS, int(tids[i]), 1, qn, MUSIC_AMP, MUSIC_BED, MUSIC_BURST,
+                                                  int(starts[i]), _ffi.vp(sig.ptr + i * qn * 2)))
+        else:
+            ctx.check(_ffi.lib().shz_synth_pcm(ctx.h, SEED_TRACKS, int(tids[i]), 1, qn, tone_amp, noise_amp, int(starts[i]),
+                                               _ffi.vp(sig.ptr + i * qn * 2)))
+    if corpus == "music":
+        ctx.synth_corpus(2, SEED_NOISE, noise_clip0, nb, qn, TRAFFIC_AMP, 0, 0, 0, out=noi)
+    else:
+        ctx.synth_pcm(SEED_NOISE, noise_clip0, nb, qn, 0, 8000, out=noi)
     q = ctx.mix_snr(sig, noi, nb, qn, snr) if snr < 200 else sig
     return q, [b for b in (sig, noi, q) if b is not None]
 
 
 def run_queries(ctx, tbl, songs, n_samples, nq, qn, snr, match_batch, topn=2, tone_amp=4000, noise_amp=1500, seed=99,
-                before_batch=None):
+                before_batch=None, corpus="tonal"):
     """nq queries in batches of match_batch: fingerprint + match, wall time of the match call per batch.
     Returns a dict with per-batch milliseconds (whole batch), accuracy and the rows/pairs the match touched."""
     rng = np.random.default_rng(seed)
@@ -114,7 +132,7 @@ def run_queries(ctx, tbl, songs, n_samples, nq, qn, snr, match_batch, topn=2, to
         nb = min(match_batch, nq - b0)
         if before_batch:
             before_batch()
-        q, bufs = make_queries(ctx, tids[b0:b0 + nb], starts[b0:b0 + nb], qn, snr, tone_amp, noise_amp, b0)
+        q, bufs = make_queries(ctx, tids[b0:b0 + nb], starts[b0:b0 + nb], qn, snr, tone_amp, noise_amp, b0, corpus)
         qoff = np.arange(nb + 1, dtype=np.uint64) * qn
         ctx.sync()
         t0 = time.perf_counter()
@@ -157,6 +175,8 @@ def main():
     ap.add_argument("--finalize-every", type=int, default=0, help="songs between intermediate finalize calls (0 = once at the end)")
     ap.add_argument("--mixed-ingest", type=int, default=0, help="songs ingested (fingerprint + insert + finalize) before every "
                     "query batch: the mixed ingest + query stream of BASELINE configs[4]; 0 = queries only")
+    ap.add_argument("--corpus", choices=("tonal", "music"), default="tonal", help="tonal: six sinusoids + white noise, white query "
+                    "noise; music: music-like tracks under traffic-like query noise")
     ap.add_argument("--shards", type=int, default=1, help="partition the table by key into this many shards on the GPU "
                     "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
     a = ap.parse_args()
@@ -165,7 +185,7 @@ def main():
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     n_samples = int(round(a.seconds * FS))
     tbl, build, (kbuf, tbuf, cap) = build_table(ctx, a.songs, a.seconds, a.chunk, a.tone_amp, a.noise_amp,
-                                                a.finalize_every, a.shards)
+                                                a.finalize_every, a.shards, corpus=a.corpus)
     rows = build["rows"]
 
     qn = int(round(a.query_seconds * FS))
@@ -176,7 +196,7 @@ def main():
 
     def ingest_batch():   # new songs arrive between the query batches; their ids continue after the base corpus
         c0 = a.songs + mixed["songs"]
-        ctx.synth_pcm(SEED_TRACKS, c0, n_mix, n_samples, a.tone_amp, a.noise_amp, out=mix_pcm)
+        synth_tracks(ctx, a.corpus, c0, n_mix, n_samples, a.tone_amp, a.noise_amp, mix_pcm)
         ctx.sync()
         t0 = time.perf_counter()
         _, _, ho_m, _ = ctx.fingerprint_batch(mix_pcm, np.arange(n_mix + 1, dtype=np.uint64) * n_samples, fs=FS,
@@ -192,7 +212,7 @@ def main():
 
     t_stream0 = time.perf_counter()
     r = run_queries(ctx, tbl, a.songs, n_samples, nq, qn, a.snr, a.match_batch, a.topn, a.tone_amp, a.noise_amp,
-                    before_batch=ingest_batch if n_mix else None)
+                    before_batch=ingest_batch if n_mix else None, corpus=a.corpus)
     lat = r["batch_ms"] / r["sizes"]
     t_match = r["t_match"]
     out = {"metric": "query_match_ms_per_query_batched", "value": float(np.median(lat)), "unit": "ms/query",
@@ -200,7 +220,7 @@ def main():
            "batch_ms_p50": float(np.percentile(r["batch_ms"], 50)), "batch_ms_p99": float(np.percentile(r["batch_ms"], 99)),
            "ms_per_query_by_batch": [round(float(x), 5) for x in lat[:64]],
            "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
-           "config": {"workload": f"{a.songs} x {a.seconds:.0f} s tonal+noise tracks in one HBM table; {nq} x "
+           "config": {"corpus": a.corpus, "workload": f"{a.songs} x {a.seconds:.0f} s {'music-like' if a.corpus == 'music' else 'tonal+noise'} tracks in one HBM table; {nq} x "
                                   f"{a.query_seconds:.0f} s queries at arbitrary offsets, SNR {a.snr} dB, batches of {a.match_batch}",
                       "songs": a.songs, "rows": int(rows), "queries": nq, "snr_db": a.snr, "shards": a.shards},
            "top1_accuracy": r["correct"] / nq, "hashes_per_query": r["hashes"] / nq, "pairs_per_query": r["pairs"] / nq,

@@ -89,6 +89,14 @@ int32_t shz_get_kernel_ms(shz_ctx* ctx, int32_t which, float* total_ms, uint32_t
  * tone_amp = 0 -> white noise uniform in [-noise_amp, noise_amp). */
 int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
                       int32_t tone_amp, int32_t noise_amp, uint64_t start_sample, int16_t* dev_out);
+/* Music-like tracks (kind SHZ_CORPUS_MUSIC: four voices of decaying harmonic notes, percussive onsets, a quiet noise bed:
+ * amp, bed, burst) and traffic-like low-passed noise (SHZ_CORPUS_TRAFFIC: amp) -- stand-ins for what the reference's
+ * accuracy figures were measured on (real music under street noise, recognizer_test.py:39-40, 542-558), integer-only with
+ * numpy twins (oracle/synth.py: music_clip, traffic_noise).  Same addressing as shz_synth_pcm. */
+#define SHZ_CORPUS_MUSIC 1u
+#define SHZ_CORPUS_TRAFFIC 2u
+int32_t shz_synth_corpus(shz_ctx* ctx, uint32_t kind, uint64_t seed, uint64_t clip0, uint32_t n_clips, uint64_t n_samples,
+                         int32_t amp, int32_t bed, int32_t burst, uint64_t start_sample, int16_t* dev_out);
 
 /* HBM bandwidth probe (the measured ceiling beside the vendor peak): mode 0 copy (bytes read +
  * bytes written are counted), 1 read only, 2 write only; two scratch buffers of `bytes` each are allocated and

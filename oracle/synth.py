@@ -117,3 +117,78 @@ def tie_inputs() -> dict:
     out["sparse_clicks_5s"] = np.zeros(220500, np.int16)
     out["sparse_clicks_5s"][[30000, 30001, 90000, 150017]] = [32767, -32768, 15000, 9000]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Music-like corpus.  The tonal+noise clips above lose their peaks to a query's noise (the tracks'
+# own peaks are mostly noise-born); the reference's 0.82 at SNR 0 was measured on real music under low-passed traffic
+# noise (recognizer_test.py:39-40, 542-558; tests_csv/shazam_results_100records_5sec_0SNR.csv).  Stand-ins, integer-only
+# and random-access like synth_clip (bit-identical twin on the device: shz_synth_corpus, kinds 1 and 2):
+#
+#   music(c, n)   = four voices of notes + percussive onsets + a quiet white bed.  Voice v changes note every
+#                   L_v = 2^MUSIC_LEN_SHIFT[v] samples; note k of voice v: r = splitmix64(~key + (v << 40) + k); silent if
+#                   r >> 60 == 0; fundamental = degree (r >> 8) % 48 of an equal-tempered scale from 110 Hz (MUSIC_OMEGA,
+#                   integers) times MUSIC_OCTAVE[v], detuned by a factor (63488 + (r >> 24 & 4095)) / 65536; eight harmonics h with amplitudes amp * MUSIC_HARM[h-1] >> 8, start
+#                   phases h * (r >> 16); linear decay over the note (L - m).  Voice 0's notes open with a decaying
+#                   pseudo-random burst of 2,048 samples (amplitude `burst`): broadband, but with a texture of its own.
+#                   ~9,000 hashes per 30 s (the reference's real music: 11-12 k per song).
+#   traffic(c, n) = box-car sum of 16 consecutive white samples (a low-pass at ~1.3 kHz, -13 dB side lobes): most of its
+#                   power sits below the bins music peaks live in, like street noise.
+MUSIC_LEN_SHIFT = (14, 15, 13, 12)      # note lengths 0.37 s, 0.74 s, 0.19 s, 0.09 s
+MUSIC_OCTAVE = (1, 1, 1, 2)
+MUSIC_VOICES = len(MUSIC_LEN_SHIFT)
+MUSIC_NHARM = 8
+MUSIC_HARM = (256, 200, 150, 120, 100, 80, 64, 50)
+MUSIC_OMEGA = tuple(int(round(2 ** 32 * 110.0 * 2 ** (s / 12.0) / 44100.0)) for s in range(48))
+MUSIC_BURST_LEN = 2048
+TRAFFIC_TAPS = 16
+
+
+def music_clip(seed: int, clip: int, n_samples: int, amp: int = 3000, bed: int = 100, start: int = 0,
+               burst: int = 1500) -> np.ndarray:
+    """Samples [start, start + n_samples) of music-like clip ``clip``."""
+    key = clip_key(seed, clip)
+    n = np.arange(start, start + n_samples, dtype=U64)
+    lut = sine_lut().astype(np.int64)
+    om_tab = np.array(MUSIC_OMEGA, dtype=U64)
+    with np.errstate(over="ignore"):
+        acc = np.zeros(n_samples, np.int64)
+        if bed > 0:
+            u = splitmix64(key + n) >> U64(32)
+            acc += ((u * U64(2 * bed)) >> U64(32)).astype(np.int64) - bed
+        for v in range(MUSIC_VOICES):
+            sh = MUSIC_LEN_SHIFT[v]
+            k = n >> U64(sh)
+            m = n & U64((1 << sh) - 1)
+            r = splitmix64(~key + (U64(v) << U64(40)) + k)
+            on = (r >> U64(60)) != U64(0)
+            # scale degree, octave of the voice, and a detune of up to +-3 % drawn per note (singers and strings are not
+            # keyboards: without it a corpus of 100,000 tracks shares a few hundred peak frequencies, and every hash of a
+            # query matches tens of thousands of rows)
+            om = (om_tab[((r >> U64(8)) % U64(48)).astype(np.int64)] * U64(MUSIC_OCTAVE[v]) *
+                  (U64(63488) + ((r >> U64(24)) & U64(0xFFF)))) >> U64(16)
+            env = (U64(1 << sh) - m).astype(np.int64)                       # L .. 1
+            s = np.zeros(n_samples, np.int64)
+            for h in range(1, MUSIC_NHARM + 1):
+                ph = ((r >> U64(16)) * U64(h) + m * om * U64(h)) & U64(0xFFFFFFFF)
+                s += lut[(ph >> U64(20)).astype(np.int64)] * MUSIC_HARM[h - 1]
+            # lut (15 bits) x harm (8 bits) x env (sh bits) x amp: scaled back to ~amp at full envelope
+            acc += np.where(on, (((s * env) >> (sh + 8)) * amp) >> 15, 0)
+            if v == 0 and burst > 0:
+                ub = splitmix64(r + m) >> U64(32)
+                nb = ((ub * U64(2 * burst)) >> U64(32)).astype(np.int64) - burst
+                e2 = np.maximum(MUSIC_BURST_LEN - m.astype(np.int64), 0)
+                acc += np.where(on, (nb * e2) >> 11, 0)
+    return np.clip(acc, -32768, 32767).astype(np.int16)
+
+
+def traffic_noise(seed: int, clip: int, n_samples: int, amp: int = 2000, start: int = 0) -> np.ndarray:
+    """Low-passed noise: sum of TRAFFIC_TAPS consecutive white samples, each uniform in [-amp, amp), >> 2."""
+    key = clip_key(seed, clip)
+    n = np.arange(start, start + n_samples, dtype=U64)
+    with np.errstate(over="ignore"):
+        acc = np.zeros(n_samples, np.int64)
+        for i in range(TRAFFIC_TAPS):
+            u = splitmix64(key + n + U64(i)) >> U64(32)
+            acc += ((u * U64(2 * amp)) >> U64(32)).astype(np.int64) - amp
+    return np.clip(acc >> 2, -32768, 32767).astype(np.int16)

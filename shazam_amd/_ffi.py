@@ -38,6 +38,8 @@ SIGNATURES = {
     "shz_set_profiling": (C.c_int32, [vp, C.c_int32]),
     "shz_get_kernel_ms": (C.c_int32, [vp, C.c_int32, C.POINTER(C.c_float), u32p]),
     "shz_synth_pcm": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, vp]),
+    "shz_synth_corpus": (C.c_int32, [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_uint64, vp]),
     "shz_sumsq_i16": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint64, u64p]),
     "shz_mix_i16": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint64, f64p, vp]),
     "shz_membw": (C.c_int32, [vp, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
@@ -296,6 +298,18 @@ class Context:
             k = min(65535, n_clips - done)
             self.check(lib().shz_synth_pcm(self.h, seed, clip0 + done, k, n_samples, tone_amp, noise_amp, start,
                                            vp(out.ptr + done * n_samples * 2)))
+            done += k
+        return out
+
+    def synth_corpus(self, kind, seed, clip0, n_clips, n_samples, amp=3000, bed=100, burst=1500, start=0, out: DevBuf = None) -> DevBuf:
+        """Music-like tracks (kind 1) or traffic-like noise (kind 2) on the device (twins: oracle/synth.music_clip / traffic_noise)."""
+        if out is None:
+            out = self.alloc(int(n_clips) * int(n_samples) * 2)
+        done = 0
+        while done < n_clips:
+            k = min(65535, n_clips - done)
+            self.check(lib().shz_synth_corpus(self.h, int(kind), seed, clip0 + done, k, n_samples, amp, bed, burst, start,
+                                              vp(out.ptr + done * n_samples * 2)))
             done += k
         return out
 

@@ -481,6 +481,105 @@ extern "C" int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, ui
 }
 
 // ---------------------------------------------------------------------------------------
+// Music-like corpus and traffic-like noise (numpy twins: oracle/synth.music_clip / traffic_noise, bit for bit).
+// Stand-ins for what the reference's accuracy was measured on (real music under low-passed street noise,
+// recognizer_test.py:39-40, 542-558); integer-only and random-access like synth_pcm_kernel.
+#define MUS_VOICES 4
+#define MUS_NHARM 8
+#define MUS_BURST_LEN 2048
+__constant__ uint32_t c_mus_omega[48] = {
+    10713070u, 11350103u, 12025015u, 12740059u, 13497623u, 14300233u, 15150569u, 16051469u, 17005939u, 18017165u, 19088521u,
+    20223584u, 21426141u, 22700205u, 24050030u, 25480119u, 26995246u, 28600467u, 30301139u, 32102938u, 34011878u, 36034330u,
+    38177043u, 40447168u, 42852281u, 45400411u, 48100060u, 50960238u, 53990491u, 57200933u, 60602278u, 64205876u, 68023757u,
+    72068660u, 76354085u, 80894335u, 85704563u, 90800821u, 96200119u, 101920476u, 107980983u, 114401866u, 121204555u,
+    128411753u, 136047513u, 144137319u, 152708170u, 161788671u};
+__constant__ int c_mus_shift[MUS_VOICES] = {14, 15, 13, 12};
+__constant__ int c_mus_octave[MUS_VOICES] = {1, 1, 1, 2};
+__constant__ int c_mus_harm[MUS_NHARM] = {256, 200, 150, 120, 100, 80, 64, 50};
+
+template <int KIND>   // 1: music (amp, bed, burst), 2: traffic noise (amp)
+__global__ __launch_bounds__(256) void synth_corpus_kernel(int16_t* __restrict__ out, uint64_t seed, uint64_t clip0,
+                                                           uint64_t n_samples, uint64_t start, int amp, int bed, int burst,
+                                                           const int16_t* __restrict__ lut) {
+  const uint64_t clip = blockIdx.y;
+  const uint64_t key = splitmix64(seed * 0xD6E8FEB86659FD93ull + clip0 + clip);
+  int16_t* dst = out + clip * n_samples;
+  for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; base < n_samples;
+       base += (uint64_t)gridDim.x * blockDim.x * 8) {
+    int16_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t n = start + base + i;
+      long long acc = 0;
+      if (KIND == 1) {
+        if (bed > 0) {
+          const uint64_t u = splitmix64(key + n) >> 32;
+          acc += (long long)((u * (uint64_t)(2 * bed)) >> 32) - bed;
+        }
+#pragma unroll
+        for (int vc = 0; vc < MUS_VOICES; ++vc) {
+          const int sh = c_mus_shift[vc];
+          const uint64_t k = n >> sh, m = n & ((1ull << sh) - 1);
+          const uint64_t r = splitmix64(~key + ((uint64_t)vc << 40) + k);
+          if ((r >> 60) == 0) continue;
+          const uint64_t om = ((uint64_t)c_mus_omega[(r >> 8) % 48] * (uint64_t)c_mus_octave[vc] * (63488ull + ((r >> 24) & 0xFFFull))) >> 16;   // +-3 % detune per note
+          const long long env = (long long)((1ull << sh) - m);
+          long long s = 0;
+#pragma unroll
+          for (int h = 1; h <= MUS_NHARM; ++h) {
+            const uint32_t ph = (uint32_t)((r >> 16) * (uint64_t)h + m * om * (uint64_t)h);
+            s += (long long)lut[ph >> 20] * c_mus_harm[h - 1];
+          }
+          acc += (((s * env) >> (sh + 8)) * amp) >> 15;
+          if (vc == 0 && burst > 0) {
+            const uint64_t ub = splitmix64(r + m) >> 32;
+            const long long nb = (long long)((ub * (uint64_t)(2 * burst)) >> 32) - burst;
+            const long long e2 = (long long)MUS_BURST_LEN - (long long)m;
+            if (e2 > 0) acc += (nb * e2) >> 11;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const uint64_t u = splitmix64(key + n + (uint64_t)t) >> 32;
+          acc += (long long)((u * (uint64_t)(2 * amp)) >> 32) - amp;
+        }
+        acc >>= 2;
+      }
+      acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+      v[i] = (int16_t)acc;
+    }
+    if (base + 8 <= n_samples && ((clip * n_samples + base) & 7) == 0) {
+      *reinterpret_cast<uint4*>(dst + base) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      for (int i = 0; i < 8 && base + i < n_samples; ++i) dst[base + i] = v[i];
+    }
+  }
+}
+
+extern "C" int32_t shz_synth_corpus(shz_ctx* ctx, uint32_t kind, uint64_t seed, uint64_t clip0, uint32_t n_clips,
+                                    uint64_t n_samples, int32_t amp, int32_t bed, int32_t burst, uint64_t start_sample,
+                                    int16_t* dev_out) {
+  if (!ctx || !dev_out) return SHZ_E_INVALID;
+  if (n_clips == 0 || n_samples == 0) return SHZ_OK;
+  if (kind != SHZ_CORPUS_MUSIC && kind != SHZ_CORPUS_TRAFFIC) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_corpus: kind %u", kind);
+  if (n_clips > 65535) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_corpus: at most 65535 clips per call (got %u)", n_clips);
+  if (amp < 0 || bed < 0 || burst < 0 || amp > 8000 || bed > 32768 || burst > 32768)
+    SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_corpus: amp in [0,8000], bed and burst in [0,32768]");
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t per = (n_samples + 8 * 256 - 1) / (8 * 256);
+  dim3 grid((unsigned)(per > 4096 ? 4096 : per), n_clips);
+  if (kind == SHZ_CORPUS_MUSIC)
+    hipLaunchKernelGGL(synth_corpus_kernel<1>, grid, dim3(256), 0, ctx->stream, dev_out, seed, clip0, n_samples, start_sample, amp,
+                       bed, burst, ctx->d_sine_lut);
+  else
+    hipLaunchKernelGGL(synth_corpus_kernel<2>, grid, dim3(256), 0, ctx->stream, dev_out, seed, clip0, n_samples, start_sample, amp,
+                       bed, burst, ctx->d_sine_lut);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Query preparation on the device (bench / tests): exact integer sum of squares per clip and
 // signal + scale * noise re-quantised to int16 -- the digital form of the reference's noise
 // mixing (recognizer_test.py:426-435, 557).  The scale itself is computed on the host from the
