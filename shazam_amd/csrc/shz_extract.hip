@@ -864,6 +864,137 @@ __global__ void xctl_advance_kernel(xctl* c, uint32_t cap_peaks, bool hashes) {
   c->peak_base += c->sub_peaks < cap_peaks ? c->sub_peaks : cap_peaks;
   if (hashes) c->hash_base += c->sub_hashes;
 }
+// ---- the whole tail of a SMALL sub-batch in one workgroup ------------------------------------------------------------
+// One 5-10 s query is ~100-200 frames, ~500-1,000 peaks, ~2,000-4,000 hashes: the thirteen launches between peak_verify and
+// the read-back (scan of the per-frame counts, bookkeeping, frame times, mask expansion, per-clip offsets, partner counts,
+// their scan, the hash write, per-clip hash offsets, offsets out, advance) cost ~4.7 us each and did microseconds of work.
+// Here one workgroup walks the mask in word order -- the exclusive prefix of the words' popcounts IS the peak index
+// (__init__.py:155,194-195: peaks ordered by time, then frequency, per clip) -- and does the rest on the list it wrote.
+// Same results as the separate kernels, bit for bit (tests/test_gpu_extract.py runs both on the same inputs).
+#define XT_THREADS 1024
+#define XT_MAX_WORDS (XT_THREADS * 160)   // 4,096 frames of 40 mask words
+#define XT_MAX_PEAKS 65536
+
+__device__ __forceinline__ uint32_t xt_block_scan(uint32_t v, uint32_t* total, uint32_t* tmp) {   // exclusive, 1024 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();   // tmp may still be read from the previous use
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < XT_THREADS / 64; ++w) {
+    const uint32_t x = tmp[w];
+    if (w < wave) woff += x;
+    tot += x;
+  }
+  *total = tot;
+  return woff + inc - v;
+}
+// last index lo in [0, n) with a[lo] <= x (a ascending, a[0] <= x)
+__device__ __forceinline__ uint32_t xt_last_le(const uint32_t* __restrict__ a, uint32_t n, uint32_t x) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(XT_THREADS) void extract_tail_small_kernel(
+    const uint64_t* __restrict__ mask, uint32_t n_words, mask_geom mg, const uint32_t* __restrict__ clip_foff, uint32_t nc,
+    uint32_t c0, xctl* __restrict__ ctl, uint32_t cap_peaks, uint32_t und_cap, uint32_t fan, uint16_t* __restrict__ pf,
+    uint32_t* __restrict__ pt, uint32_t* __restrict__ pc /* nc + 1 */, uint32_t* __restrict__ hoff /* cap_peaks */,
+    uint32_t* __restrict__ key32, uint32_t* __restrict__ t1out, uint64_t o_cap, unsigned long long* __restrict__ out64) {
+  __shared__ uint32_t tmp[XT_THREADS / 64];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per_frame = mg.n_slabs * mg.nw;
+  const unsigned long long hash_base = ctl->hash_base;
+  // A. mask -> ordered peak list; pc[c] = index of clip c's first peak
+  uint32_t base = 0;
+  for (uint32_t w0 = 0; w0 < n_words; w0 += XT_THREADS) {
+    const uint32_t w = w0 + tid;
+    uint64_t m = w < n_words ? mask[w] : 0ull;
+    uint32_t tot;
+    uint32_t o = base + xt_block_scan((uint32_t)__popcll(m), &tot, tmp);
+    if (w < n_words) {
+      const uint32_t g = w / per_frame, rem = w - g * per_frame;
+      if (rem == 0 || m) {
+        const uint32_t lo = xt_last_le(clip_foff, nc, g);
+        if (rem == 0 && clip_foff[lo] == g) pc[lo] = o < cap_peaks ? o : cap_peaks;   // first word of the clip's first frame
+        const uint32_t slab = rem / mg.nw, wv = rem % mg.nw, t = g - clip_foff[lo];
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          if (o < cap_peaks) {
+            pf[o] = (uint16_t)(slab * mg.sw + wv * mg.lane_stride + b - 10);
+            pt[o] = t;
+          }
+          ++o;
+        }
+      }
+    }
+    base += tot;
+  }
+  const uint32_t sub_peaks = base, n_peaks = sub_peaks < cap_peaks ? sub_peaks : cap_peaks;
+  if (tid == 0) pc[nc] = n_peaks;
+  __syncthreads();   // the list and pc are complete (global writes of this workgroup, read below by other threads)
+  // B. partners of every peak, their prefix = the hash index; (key32, t1) written in (i, j) generation order
+  uint32_t hbase = 0;
+  for (uint32_t i0 = 0; i0 < n_peaks; i0 += XT_THREADS) {
+    const uint32_t i = i0 + tid;
+    uint32_t c = 0, endp = 0, t1 = 0;
+    if (i < n_peaks) {
+      endp = pc[xt_last_le(pc, nc, i) + 1];   // (clips without peaks share an offset: the last of them is the peak's clip)
+      t1 = pt[i];
+      for (uint32_t jn = 1; jn < fan; ++jn) {
+        if (i + jn >= endp) break;
+        if (pt[i + jn] - t1 <= SHZ_MAX_DT) ++c;   // sorted by time: dt >= 0 = MIN_HASH_TIME_DELTA
+      }
+    }
+    uint32_t tot;
+    const uint32_t h0 = hbase + xt_block_scan(c, &tot, tmp);
+    if (i < n_peaks) {
+      hoff[i] = h0;
+      const uint32_t f1 = pf[i];
+      uint64_t o = hash_base + h0;
+      for (uint32_t jn = 1; jn < fan; ++jn) {
+        if (i + jn >= endp) break;
+        const uint32_t dt = pt[i + jn] - t1;
+        if (dt <= SHZ_MAX_DT) {
+          if (o < o_cap) {
+            key32[o] = (f1 << 20) | ((uint32_t)pf[i + jn] << 8) | dt;
+            t1out[o] = t1;
+          }
+          ++o;
+        }
+      }
+    }
+    hbase += tot;
+  }
+  __syncthreads();
+  // C. per-clip hash offsets of the call, bookkeeping
+  for (uint32_t c = tid; c < nc; c += XT_THREADS) {
+    const uint32_t p1 = pc[c + 1];
+    out64[c0 + c + 1] = hash_base + (p1 < n_peaks ? hoff[p1] : hbase);
+  }
+  if (tid == 0) {
+    if (c0 == 0) out64[0] = 0;
+    ctl->sub_peaks = sub_peaks;
+    ctl->sub_hashes = hbase;
+    if (sub_peaks > cap_peaks) ctl->flags |= XF_PEAK_CAP;
+    if (sub_peaks > ctl->max_sub_peaks) ctl->max_sub_peaks = sub_peaks;
+    if (ctl->und_count > und_cap) ctl->flags |= XF_UND_CAP | XF_FALLBACK;
+    ctl->peak_base += n_peaks;
+    ctl->hash_base = hash_base + hbase;
+  }
+}
+
 // append this sub-batch's peak list to the output arrays at peak_base
 __global__ __launch_bounds__(256) void peaks_out_kernel(const xctl* c, const uint16_t* __restrict__ pf,
                                                         const uint32_t* __restrict__ pt, uint32_t cap_peaks,
@@ -1468,6 +1599,18 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
                            1.0, sd.d_foff, nc);
         SHZ_HIP(ctx, hipGetLastError());
       }
+    }
+    static const bool no_small_tail = [] { const char* e = getenv("SHZ_NO_SMALL_TAIL"); return e && atoi(e) != 0; }();
+    if (want_hashes && !no_small_tail && n_words && n_words <= XT_MAX_WORDS && cap_peaks <= XT_MAX_PEAKS) {
+      shz_prof_scope ps(ctx, 3);
+      void* d_hoff;
+      SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)cap_peaks * 4 + 64, &d_hoff));
+      hipLaunchKernelGGL(extract_tail_small_kernel, dim3(1), dim3(XT_THREADS), 0, ctx->stream, (const uint64_t*)d_mask,
+                         (uint32_t)n_words, mg, (const uint32_t*)sd.d_foff, nc, sb.c0, d_ctl, cap_peaks, (uint32_t)UND_CAP, fan,
+                         (uint16_t*)pf, (uint32_t*)pt, (uint32_t*)pc, (uint32_t*)d_hoff, (uint32_t*)o_a, (uint32_t*)o_b, o_cap, d_offs);
+      SHZ_HIP(ctx, hipGetLastError());
+      if (overlap) SHZ_HIP(ctx, hipEventRecord(ctx->ev_free[si & 1], ctx->stream));
+      continue;
     }
     {
       shz_prof_scope ps(ctx, 2);
