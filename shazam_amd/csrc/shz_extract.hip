@@ -1759,16 +1759,44 @@ static int32_t splice_f64_clips(shz_ctx* ctx, const int16_t* pcm, const uint64_t
   const uint64_t b_a = want_hashes ? 4 : 2;
   const bool saved = ctx->stage_f64;
   struct restore { shz_ctx* c; bool v; ~restore() { c->stage_f64 = v; } } rs{ctx, saved};
-  struct redo { uint64_t cnt = 0; std::vector<uint32_t> b, a32; std::vector<uint16_t> a16; };
+  struct redo { uint64_t cnt = 0, dev_at = 0; bool on_dev = false; std::vector<uint32_t> b, a32; std::vector<uint16_t> a16; };
   std::vector<redo> R(flagged.size());
-  // 1) every flagged clip once more, fp64 staging, entries to the host
-  uint64_t new_total = *total;
+  // 1) every flagged clip once more, fp64 staging.  Device outputs: the clip's new entries go straight behind the batch's
+  // entries in the caller's arrays (the room is there or the call ends in SHZ_E_CAPACITY anyway) and are moved into place on
+  // the device; host outputs: to host vectors.
+  uint64_t new_total = *total, dev_end = *total;
   for (size_t fi = 0; fi < flagged.size(); ++fi) {
     const uint32_t c = flagged[fi];
     redo& r = R[fi];
     const uint64_t frames_c = shz_frame_count(clip_off[c + 1] - clip_off[c]);
     uint64_t cap_c = frames_c * 64 * (want_hashes ? (fan > 1 ? fan - 1 : 1) : 1) + 4096;
     uint64_t o2[2] = {0, 0};
+    if (out_dev) {
+      const uint64_t at = (dev_end + 63) & ~63ull;   // (16-byte aligned for 2- and 4-byte entries)
+      if (at < cap) {
+        ctx->stage_f64 = true;
+        const int32_t rc = extract_driver(ctx, pcm, clip_off + c, 1, fs, amp_min, fan, flags, want_hashes,
+                                          want_hashes ? nullptr : (uint16_t*)A + at, want_hashes ? nullptr : (uint32_t*)B + at,
+                                          want_hashes ? nullptr : o2, want_hashes ? (uint32_t*)A + at : nullptr,
+                                          want_hashes ? (uint32_t*)B + at : nullptr, want_hashes ? o2 : nullptr, cap - at, &r.cnt);
+        ctx->stage_f64 = saved;
+        if (rc == SHZ_OK) {
+          r.on_dev = true;
+          r.dev_at = at;
+          dev_end = at + r.cnt;
+          ++ctx->st_f64_clips;
+          ctx->st_f64_frames += frames_c;
+          new_total = new_total - (offs[c + 1] - offs[c]) + r.cnt;
+          continue;
+        }
+        if (rc != SHZ_E_CAPACITY) return rc;
+        // no room behind the batch: what the caller has to provide is at least this
+        *total = std::max(new_total - (offs[c + 1] - offs[c]) + r.cnt, at + r.cnt);
+        SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs at least %llu entries, capacity %llu", (unsigned long long)*total, (unsigned long long)cap);
+      }
+      *total = cap + cap_c;
+      SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs more than %llu entries", (unsigned long long)cap);
+    }
     for (int attempt = 0;; ++attempt) {
       r.b.resize(cap_c);
       if (want_hashes) r.a32.resize(cap_c); else r.a16.resize(cap_c);
@@ -1787,39 +1815,56 @@ static int32_t splice_f64_clips(shz_ctx* ctx, const int16_t* pcm, const uint64_t
     new_total = new_total - (offs[c + 1] - offs[c]) + r.cnt;
   }
   // 2) room for the result?  (*total = what the caller has to provide)
-  if (new_total > cap) {
+  if (new_total > cap || (out_dev && dev_end > cap)) {
     *total = new_total;
     SHZ_FAIL(ctx, SHZ_E_CAPACITY, "output needs %llu entries, capacity %llu", (unsigned long long)new_total, (unsigned long long)cap);
   }
-  // 3) splice, from the back: the offsets in front of a clip stay what they are
+  // 3) splice
+  if (out_dev) {
+    // the final arrays are put together in scratch -- the stretches between flagged clips from the batch's entries, a
+    // flagged clip's entries from where they were parked -- and copied back: 2 |flagged| + 2 device copies per array
+    void* tmp;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, std::max<uint64_t>(new_total, 1) * 4 + 64, &tmp));
+    for (int arr = 0; arr < 2; ++arr) {
+      char* base = arr == 0 ? (char*)A : (char*)B;
+      const uint64_t bs = arr == 0 ? b_a : 4;
+      uint64_t src = 0, dst = 0;   // entries of the old arrays consumed / of the new arrays written
+      for (size_t fi = 0; fi < flagged.size(); ++fi) {
+        const uint32_t c = flagged[fi];
+        const uint64_t keep = offs[c] - src;   // unflagged entries in front of the clip
+        if (keep) SHZ_HIP(ctx, hipMemcpyAsync((char*)tmp + dst * bs, base + src * bs, keep * bs, hipMemcpyDeviceToDevice, ctx->stream));
+        dst += keep;
+        if (R[fi].cnt) SHZ_HIP(ctx, hipMemcpyAsync((char*)tmp + dst * bs, base + R[fi].dev_at * bs, R[fi].cnt * bs, hipMemcpyDeviceToDevice, ctx->stream));
+        dst += R[fi].cnt;
+        src = offs[c + 1];
+      }
+      const uint64_t rest = *total - src;
+      if (rest) SHZ_HIP(ctx, hipMemcpyAsync((char*)tmp + dst * bs, base + src * bs, rest * bs, hipMemcpyDeviceToDevice, ctx->stream));
+      dst += rest;
+      if (dst) SHZ_HIP(ctx, hipMemcpyAsync(base, tmp, dst * bs, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t fi = flagged.size(); fi-- > 0;) {
+      const uint32_t c = flagged[fi];
+      const uint64_t old = offs[c + 1] - offs[c];
+      for (uint32_t i = c + 1; i <= n_clips; ++i) offs[i] = offs[i] - old + R[fi].cnt;
+    }
+    *total = new_total;
+    return SHZ_OK;
+  }
+  // host arrays: from the back, so that the offsets in front of a clip stay what they are
   for (size_t fi = flagged.size(); fi-- > 0;) {
     const uint32_t c = flagged[fi];
     const redo& r = R[fi];
     const uint64_t cnt = r.cnt, old0 = offs[c], old1 = offs[c + 1], tail = *total - old1;
     const void* src_a = want_hashes ? (const void*)r.a32.data() : (const void*)r.a16.data();
-    if (out_dev) {
-      if (cnt != old1 - old0 && tail) {   // the entries behind the clip move: through scratch (the ranges overlap)
-        void* tmp;
-        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, tail * 4, &tmp));
-        SHZ_HIP(ctx, hipMemcpyAsync(tmp, (char*)A + old1 * b_a, tail * b_a, hipMemcpyDeviceToDevice, ctx->stream));
-        SHZ_HIP(ctx, hipMemcpyAsync((char*)A + (old0 + cnt) * b_a, tmp, tail * b_a, hipMemcpyDeviceToDevice, ctx->stream));
-        SHZ_HIP(ctx, hipMemcpyAsync(tmp, (char*)B + old1 * 4, tail * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        SHZ_HIP(ctx, hipMemcpyAsync((char*)B + (old0 + cnt) * 4, tmp, tail * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      }
-      if (cnt) {
-        SHZ_HIP(ctx, shz_memcpy(ctx, (char*)A + old0 * b_a, src_a, cnt * b_a, hipMemcpyHostToDevice));
-        SHZ_HIP(ctx, shz_memcpy(ctx, (char*)B + old0 * 4, r.b.data(), cnt * 4, hipMemcpyHostToDevice));
-      }
-      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } else {
-      if (cnt != old1 - old0 && tail) {
-        memmove((char*)A + (old0 + cnt) * b_a, (char*)A + old1 * b_a, tail * b_a);
-        memmove((char*)B + (old0 + cnt) * 4, (char*)B + old1 * 4, tail * 4);
-      }
-      if (cnt) {
-        memcpy((char*)A + old0 * b_a, src_a, cnt * b_a);
-        memcpy((char*)B + old0 * 4, r.b.data(), cnt * 4);
-      }
+    if (cnt != old1 - old0 && tail) {
+      memmove((char*)A + (old0 + cnt) * b_a, (char*)A + old1 * b_a, tail * b_a);
+      memmove((char*)B + (old0 + cnt) * 4, (char*)B + old1 * 4, tail * 4);
+    }
+    if (cnt) {
+      memcpy((char*)A + old0 * b_a, src_a, cnt * b_a);
+      memcpy((char*)B + old0 * 4, r.b.data(), cnt * 4);
     }
     for (uint32_t i = c + 1; i <= n_clips; ++i) offs[i] = offs[i] - (old1 - old0) + cnt;
     *total = *total - (old1 - old0) + cnt;
