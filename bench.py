@@ -301,7 +301,9 @@ def db_build_scaling(a, ctx, dist, comm, rank, world):
     rows_total = int(songs * frames * bench_db.ROWS_PER_FRAME_HINT)
     rows_local = int((hi - lo) * frames * bench_db.ROWS_PER_FRAME_HINT)
     tbl = Table(ctx)
-    tbl.reserve(rows_total, rows_local, gather=world > 1)
+    # setup, outside the timed region: the table's arenas exist before the clock starts (device memory that went through
+    # hipFree earlier in the process comes back scrubbed by the driver at ~40 GB/s, and that stalls kernel launches)
+    tbl.reserve(rows_total, rows_local, gather=world > 1, wait=True)
     cap = chunk * frames * 24 + 1024
     kbuf, tbuf, pcm = ctx.alloc(cap * 4), ctx.alloc(cap * 4), ctx.alloc(chunk * n_samples * 2)
     if dist:

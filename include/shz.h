@@ -40,6 +40,7 @@ extern "C" {
 #define SHZ_IN_DEVICE 4u     /* generic: input arrays are device memory        */
 #define SHZ_STFT_POWER 8u    /* shz_stft_db: write the PSD itself, not 10*log10 */
 #define SHZ_RESERVE_GATHER 32u /* shz_table_reserve: size the run arena for an all-gathered build (every rank's rows) */
+#define SHZ_RESERVE_WAIT 64u   /* shz_table_reserve: return when the allocations exist (setup outside a timed region) */
 #define SHZ_MATCH_FULL_SORT 16u /* shz_match_batch: 8-byte votes, full radix sort and record chain (the reference form of
                                   the vote: what the 4-byte votes and the vote tiles must reproduce) */
 
@@ -213,7 +214,7 @@ int32_t shz_table_finalize(shz_table* t);
  * shz_table_reserve announces how many rows the table will hold and how many arrive between two seals; ONE slab for
  * the segments' columns, the run arena, the staging columns and the sort scratch are then allocated once, on a helper
  * thread beside the first fingerprint batches, and the build performs no further device allocation.  Without it
- * everything still works, allocating as it goes.  rows_hint = 0: no-op.  flags: SHZ_RESERVE_GATHER.
+ * everything still works, allocating as it goes.  rows_hint = 0: no-op.  flags: SHZ_RESERVE_GATHER, SHZ_RESERVE_WAIT.
  * shz_table_seal_run turns the staged rows into a sorted run (bounded scratch: one batch) WITHOUT making them visible
  * to queries; full segments are cut as soon as enough rows wait; shz_table_finalize merges what is left (k-way merge of
  * the runs, 8 bytes read + 12 written per row) and makes everything visible.  On a table whose active segment holds

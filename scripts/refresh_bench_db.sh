@@ -5,7 +5,7 @@ TAG=${1:-r02}
 O=gpurun_out; mkdir -p $O
 B="timeout -k 10 900 python bench_db.py"
 # configs[2]/[3] as written: 100k x 3 min tracks, 10k x 5 s queries at SNR 0 dB (recognizer_test.py:39-40)
-$B --songs 100000 --seconds 180 --queries 10000 --snr 0 --match-batch 500 --chunk 500 --finalize-every 20000 > $O/${TAG}_bench_db_config3_4_100k_x_180s_snr0.json
+$B --songs 100000 --seconds 180 --queries 10000 --snr 0 --match-batch 500 --chunk 500 --finalize-every 10000 > $O/${TAG}_bench_db_config3_4_100k_x_180s_snr0.json
 $B --songs 100000 --queries 4000 --snr 10 > $O/${TAG}_bench_db_100k_snr10.json
 $B --songs 100000 --queries 4000 --snr 0 > $O/${TAG}_bench_db_100k_snr0.json
 $B --songs 100000 --queries 4000 --snr 10 --shards 4 > $O/${TAG}_bench_db_100k_snr10_shards4.json

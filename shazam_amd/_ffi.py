@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHZ_LIB") or os.path.join(_HERE, "libshz.so")  # SHZ_LIB: A/B builds of the same ABI
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NOMEM, E_UNSUPPORTED, E_RCCL, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
-PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER, MATCH_FULL_SORT, RESERVE_GATHER = 1, 2, 4, 8, 16, 32
+PCM_DEVICE, OUT_DEVICE, IN_DEVICE, STFT_POWER, MATCH_FULL_SORT, RESERVE_GATHER, RESERVE_WAIT = 1, 2, 4, 8, 16, 32, 64
 NFFT, HOP, NBINS = 4096, 2048, 2049
 
 u8p, u16p, u32p, i32p, u64p, i16p, f64p = (C.POINTER(t) for t in (
@@ -492,9 +492,11 @@ class Table:
     def finalize(self):
         self.ctx.check(lib().shz_table_finalize(self.h))
 
-    def reserve(self, rows_hint: int, batch_rows_hint: int = 0, gather: bool = False):
-        """Announce the size of a bulk build: the table's arenas are allocated once, beside the first batches."""
-        self.ctx.check(lib().shz_table_reserve(self.h, int(rows_hint), int(batch_rows_hint), RESERVE_GATHER if gather else 0))
+    def reserve(self, rows_hint: int, batch_rows_hint: int = 0, gather: bool = False, wait: bool = False):
+        """Announce the size of a bulk build: the table's arenas are allocated once, beside the first batches (wait: before
+        this call returns)."""
+        self.ctx.check(lib().shz_table_reserve(self.h, int(rows_hint), int(batch_rows_hint),
+                                               (RESERVE_GATHER if gather else 0) | (RESERVE_WAIT if wait else 0)))
 
     def seal_run(self):
         """Staged rows -> one sorted run (not yet visible to queries); finalize() merges the runs."""

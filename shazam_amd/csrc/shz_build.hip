@@ -1185,7 +1185,7 @@ extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t 
   t->job = j;
   j->th = std::thread(reserve_worker, j);
   static const bool sync_alloc = [] { const char* e = getenv("SHZ_RESERVE_SYNC"); return e && atoi(e) != 0; }();
-  if (sync_alloc) reserve_wait(t, RJ_SLAB);   // measurement aid: the allocations on the caller's clock, nothing beside them
+  if (sync_alloc || (flags & SHZ_RESERVE_WAIT)) reserve_wait(t, RJ_SLAB);   // the allocations on the caller's clock, nothing beside them
   return SHZ_OK;
 }
 
