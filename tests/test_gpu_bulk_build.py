@@ -166,3 +166,24 @@ def test_wide_ids_fall_back_to_the_column_path(env):
     assert t.rows() == (len(_uniq([(k, s, o)])), 0)
     _check_table(t, _uniq([(k, s, o)]))
     t.close()
+
+
+def test_clear_then_finalize_runs_does_not_leak(env):
+    """a rebuild from runs into a cleared table used to overwrite the active columns without freeing them."""
+    S, F, ctx = env
+    rng = np.random.default_rng(2)
+    t = F.Table(ctx)
+    free_ref = None
+    for rep in range(5):
+        k, s, o = _rows(rng, 300000, 1, 500)
+        t.insert(k, s, o)
+        t.finalize_runs([100000, 150000, 50000])
+        _check_table(t, _uniq([(k, s, o)]))
+        ctx.sync()
+        free_now = ctx.mem_info()[0]
+        if rep == 1:
+            free_ref = free_now
+        if rep > 1:
+            assert abs(free_now - free_ref) < (8 << 20), (free_ref, free_now)
+        t.clear()
+    t.close()
