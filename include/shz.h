@@ -276,6 +276,10 @@ int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, u
  * to the other ranks by the host (torch.distributed / any store). */
 int32_t shz_comm_unique_id(uint8_t id_out[128]);
 int32_t shz_comm_create(shz_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t nranks, shz_comm** out);
+/* The same communicator interface with the ranks as THREADS of one process (one context each, on one device or on several):
+ * exchanges are rendezvous + device copies out of the peers' buffers.  Lets the N > 1 logic of the sharded build run on a
+ * one-GPU box (tests), and a single process drive several GPUs without RCCL.  group_id: any number the ranks agree on. */
+int32_t shz_comm_create_local(shz_ctx* ctx, uint64_t group_id, int32_t rank, int32_t nranks, shz_comm** out);
 int32_t shz_comm_destroy(shz_comm* c);
 /* All-gather every rank's STAGED rows over RCCL/xGMI into the node-global table: afterwards every rank holds the
  * same table.  Into an empty table (the database build) every rank sorts its own rows, the sorted runs travel packed

@@ -80,6 +80,7 @@ SIGNATURES = {
     "shz_match_vt_redo": (C.c_int32, [vp, u64p]),
     "shz_comm_unique_id": (C.c_int32, [vp]),
     "shz_comm_create": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "shz_comm_create_local": (C.c_int32, [vp, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "shz_comm_destroy": (C.c_int32, [vp]),
     "shz_table_allgather": (C.c_int32, [vp, vp, u64p]),
     "shz_table_finalize_runs": (C.c_int32, [vp, u64p, C.c_uint32]),
@@ -612,6 +613,16 @@ class Comm:
         h = vp()
         ctx.check(lib().shz_comm_create(ctx.h, idb, rank, nranks, C.byref(h)))
         self.h, self.rank, self.nranks = h, rank, nranks
+
+    @classmethod
+    def local(cls, ctx: Context, group_id: int, rank: int, nranks: int) -> "Comm":
+        """Ranks = threads of this process (one Context each): rendezvous + device copies instead of RCCL."""
+        self = cls.__new__(cls)
+        self.ctx, self.h = ctx, None
+        h = vp()
+        ctx.check(lib().shz_comm_create_local(ctx.h, int(group_id), rank, nranks, C.byref(h)))
+        self.h, self.rank, self.nranks = h, rank, nranks
+        return self
 
     def barrier(self):
         self.ctx.check(lib().shz_comm_barrier(self.h))

@@ -57,11 +57,109 @@ static rccl_api* rccl() {
   return api.lib ? &api : nullptr;
 }
 
+// ---- the in-process transport: ranks are THREADS of one process (one context each, on one device or several) -------
+// Same rank protocol as over RCCL -- the table code cannot tell the difference -- but an exchange is a rendezvous of the
+// threads and device-to-device copies out of the peers' buffers.  What it is for: the N > 1 logic of the sharded build
+// (counts and layouts agreed between ranks, runs placed behind each other, the k-way merge over ranks' runs, the all-to-all
+// of the key-sharded table) runs on a ONE-GPU box, which the build leases; and a single process that drives several GPUs
+// can use it as is (copies between devices go over xGMI peer access).
+#include <condition_variable>
+#include <map>
+#include <mutex>
+struct local_group {
+  std::mutex mu;
+  std::condition_variable cv;
+  int nranks = 0, arrived = 0, attached = 0;
+  uint64_t generation = 0;
+  std::vector<const void*> send;                 // what every rank published for the exchange in flight
+  std::vector<std::vector<uint64_t>> displ;      // alltoallv: the publisher's send displacements
+  bool broken = false;                           // a rank gave up waiting: everybody fails from then on
+};
+static std::mutex g_groups_mu;
+static std::map<uint64_t, local_group*> g_groups;
+
+// rendezvous of all ranks; false after 120 s without the others (a rank died or never came)
+static bool local_barrier(local_group* g) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  if (g->broken) return false;
+  const uint64_t gen = g->generation;
+  if (++g->arrived == g->nranks) {
+    g->arrived = 0;
+    ++g->generation;
+    g->cv.notify_all();
+    return true;
+  }
+  if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->generation != gen || g->broken; })) g->broken = true;
+  if (g->broken) { g->cv.notify_all(); return false; }
+  return true;
+}
+
 struct shz_comm {
   shz_ctx* ctx;
   ncclComm_t comm;
   int rank, nranks;
+  local_group* lg = nullptr;   // non-null: the in-process transport
+  uint64_t lg_id = 0;
 };
+
+// one exchange of the in-process transport: every rank publishes its send buffer (data complete: own stream drained), all
+// meet, `copy(p, send pointer of rank p, displacements of rank p)` pulls what this rank wants from rank p, all meet again
+// (nobody touches its send buffer before every peer has read it)
+template <class F>
+static int32_t local_exchange(shz_comm* c, const void* d_send, const uint64_t* my_displ, F&& copy) {
+  shz_ctx* ctx = c->ctx;
+  local_group* g = c->lg;
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->send[c->rank] = d_send;
+    if (my_displ) g->displ[c->rank].assign(my_displ, my_displ + c->nranks);
+  }
+  if (!local_barrier(g)) SHZ_FAIL(ctx, SHZ_E_RCCL, "in-process exchange: a rank did not arrive");
+  for (int p = 0; p < c->nranks; ++p) {
+    const void* sp;
+    std::vector<uint64_t> dp;
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      sp = g->send[p];
+      if (my_displ) dp = g->displ[p];
+    }
+    const hipError_t e = copy(p, sp, dp);
+    if (e != hipSuccess) {
+      { std::lock_guard<std::mutex> lk(g->mu); g->broken = true; }
+      g->cv.notify_all();
+      SHZ_FAIL(ctx, SHZ_E_HIP, "in-process exchange: copy from rank %d failed: %s", p, hipGetErrorString(e));
+    }
+  }
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!local_barrier(g)) SHZ_FAIL(ctx, SHZ_E_RCCL, "in-process exchange: a rank did not arrive");
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_comm_create_local(shz_ctx* ctx, uint64_t group_id, int32_t rank, int32_t nranks, shz_comm** out) {
+  if (!ctx || !out || nranks < 1 || rank < 0 || rank >= nranks) return SHZ_E_INVALID;
+  local_group* g;
+  {
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    auto it = g_groups.find(group_id);
+    if (it == g_groups.end()) {
+      g = new local_group();
+      g->nranks = nranks;
+      g->send.assign(nranks, nullptr);
+      g->displ.resize(nranks);
+      g_groups[group_id] = g;
+    } else {
+      g = it->second;
+      if (g->nranks != nranks) SHZ_FAIL(ctx, SHZ_E_INVALID, "in-process group %llu has %d ranks, not %d", (unsigned long long)group_id, g->nranks, nranks);
+    }
+    ++g->attached;
+  }
+  shz_comm* cm = new shz_comm{ctx, nullptr, rank, nranks};
+  cm->lg = g;
+  cm->lg_id = group_id;
+  *out = cm;
+  return SHZ_OK;
+}
 
 #define SHZ_NCCL(ctx, call)                                                                          \
   do {                                                                                               \
@@ -97,7 +195,15 @@ extern "C" int32_t shz_comm_destroy(shz_comm* c) {
   if (!c) return SHZ_E_INVALID;
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
-  rccl()->CommDestroy(c->comm);
+  if (c->lg) {
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    if (--c->lg->attached == 0) {
+      g_groups.erase(c->lg_id);
+      delete c->lg;
+    }
+  } else {
+    rccl()->CommDestroy(c->comm);
+  }
   delete c;
   return SHZ_OK;
 }
@@ -113,6 +219,10 @@ int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks) {
 // all-gather of equal-sized byte blocks: recv must hold nranks*bytes
 int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes) {
   shz_ctx* ctx = c->ctx;
+  if (c->lg)
+    return local_exchange(c, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
+      return bytes ? hipMemcpyAsync((char*)d_recv + (uint64_t)p * bytes, sp, bytes, hipMemcpyDefault, ctx->stream) : hipSuccess;
+    });
   SHZ_NCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, NCCL_U8, c->comm, ctx->stream));
   return SHZ_OK;
 }
@@ -126,6 +236,10 @@ int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, 
 int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
                                   const uint64_t* displ) {
   shz_ctx* ctx = c->ctx;
+  if (c->lg)
+    return local_exchange(c, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
+      return counts[p] ? hipMemcpyAsync((char*)d_recv + displ[p], sp, counts[p], hipMemcpyDefault, ctx->stream) : hipSuccess;
+    });
   rccl_api* r = rccl();
   static const bool use_bcast = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "bcast"); }();
   const uint64_t PIECE = 1ull << 30;
@@ -166,6 +280,11 @@ int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv,
 int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t* scount, const uint64_t* sdispl,
                                  void* d_recv, const uint64_t* rcount, const uint64_t* rdispl) {
   shz_ctx* ctx = c->ctx;
+  if (c->lg)
+    return local_exchange(c, d_send, sdispl, [&](int p, const void* sp, const std::vector<uint64_t>& dp) {
+      return rcount[p] ? hipMemcpyAsync((char*)d_recv + rdispl[p], (const char*)sp + dp[c->rank], rcount[p], hipMemcpyDefault, ctx->stream)
+                       : hipSuccess;
+    });
   rccl_api* r = rccl();
   if (scount[c->rank] != rcount[c->rank]) SHZ_FAIL(ctx, SHZ_E_INVALID, "alltoallv: self block sizes differ");
   if (scount[c->rank])
