@@ -268,6 +268,11 @@ int32_t shz_match_batch(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const
 #define SHZ_DEBUG_VT_PROBE1 2u
 int32_t shz_set_debug(shz_ctx* ctx, uint32_t flags);
 int32_t shz_match_vt_redo(shz_ctx* ctx, uint64_t* count);
+/* A single query of at most 8,192 hashes handed over in host memory has its vote kernels queued before the number of its
+ * votes is known (they do nothing when it exceeds 32,768; the call then continues as for any other query): how many
+ * calls queued them / took their results from them, since the context was created.  Same results either way;
+ * SHZ_MATCH_NO_SPEC=1 in the environment turns the queueing off. */
+int32_t shz_match_spec_stats(shz_ctx* ctx, uint64_t* queued, uint64_t* used);
 /* rows streamed / pairs voted by the last shz_match_batch (for HBM accounting) */
 int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, uint64_t* distinct_keys);
 

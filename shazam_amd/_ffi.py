@@ -78,6 +78,7 @@ SIGNATURES = {
     "shz_match_stats": (C.c_int32, [vp, u64p, u64p, u64p]),
     "shz_set_debug": (C.c_int32, [vp, C.c_uint32]),
     "shz_match_vt_redo": (C.c_int32, [vp, u64p]),
+    "shz_match_spec_stats": (C.c_int32, [vp, u64p, u64p]),
     "shz_comm_unique_id": (C.c_int32, [vp]),
     "shz_comm_create": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "shz_comm_create_local": (C.c_int32, [vp, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(vp)]),
@@ -213,6 +214,13 @@ class Context:
         n = C.c_uint64()
         self.check(lib().shz_match_vt_redo(self.h, C.byref(n)))
         return n.value
+
+    def spec_stats(self):
+        """(queued, used): single small queries whose vote kernels were queued ahead of the vote count / that took
+        their results from them."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.check(lib().shz_match_spec_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def mem_info(self):
         """(free, total) bytes of device memory right now."""

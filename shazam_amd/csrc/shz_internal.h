@@ -99,6 +99,7 @@ struct shz_ctx {
   std::vector<struct shz_prof_rec> prof_free;
   // match stats
   uint64_t st_rows = 0, st_pairs = 0, st_keys = 0;
+  uint64_t st_spec_queued = 0, st_spec_used = 0;   // single small queries whose votes were queued ahead of the count / whose results that gave
   uint64_t st_vt_redo = 0;      // sub-batches whose vote tiles flagged an overflow and were voted again by the full sort
   uint32_t debug = 0;           // SHZ_DEBUG_* (shz_set_debug): switches that force rare paths, for tests
   // extraction stats: cells fp32 peak picking left undecided, of those decided on fp64 values, frames recomputed for

@@ -419,11 +419,11 @@ __device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t of
 // Votes [v_lo, P) of the sub-batch go to v[0 ..): VT = uint64_t, or uint32_t when a pass's queries, song ids and deltas
 // fit 31 bits (q_base then shifts the query index to the pass's first query).
 template <typename VT>
-__global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
-                                                       const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
-                                                       const uint32_t* __restrict__ g_lo,
-                                                       const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
-                                                       uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
+__device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                              const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
+                                              const uint32_t* __restrict__ g_lo,
+                                              const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                              uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
   __shared__ uint64_t s_po[M_EXP_SUB], s_e[M_EXP_SUB];
   __shared__ uint32_t s_lo[M_EXP_SUB], s_e0[M_EXP_SUB], s_noff[M_EXP_SUB], s_sg[M_EXP_SUB];
   __shared__ const uint32_t* s_sid[SHZ_MAX_SEGS];
@@ -498,6 +498,57 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
     const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
     if (pj < P) v[pj - v_lo] = (VT)out;
   }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                                       const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
+                                                       const uint32_t* __restrict__ g_lo,
+                                                       const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                                       uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
+  m_expand_tile<VT>(E, gs, tile_x, po, g_lo, segs, nseg, v_lo, P, mb, q_base, v);
+}
+
+// ---- one small query, votes queued BEFORE their number is known on the host
+// A single query against a small or medium table has a few thousand votes, and its match is a chain of short launches: the
+// read-back of the vote count in the middle of it (a stream sync, ~30 us) is a sixth of the whole call.  For one query
+// whose hashes went through m_head_small_kernel the host therefore queues the one-workgroup vote path behind the probe
+// at once, sized for VT_ONE_WG_MAX votes; these kernels read the vote count from the control block and do nothing when it
+// is larger -- the host then sees that count in the one read-back and continues as if nothing had been queued.
+//
+// m_spec_plan_kernel: tile_x of the expand tiles (as m_tile_start_kernel) + the single vote range (as vt_one_range_kernel)
+__global__ void m_spec_plan_kernel(const uint64_t* __restrict__ po, const mctl* __restrict__ ctl, uint32_t nseg, uint64_t cap,
+                                   uint32_t* __restrict__ tile_x, uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
+                                   uint32_t* __restrict__ heavy_q) {
+  const uint64_t P = ctl->P;
+  const bool ok = P > 0 && P <= cap;
+  if (threadIdx.x == 0) {
+    *n_heavy = ok ? 1u : 0u;
+    heavy[0] = make_uint2(0u, ok ? (uint32_t)P : 0u);
+    heavy_q[0] = 0u;
+  }
+  if (!ok) return;
+  const uint32_t nx = (uint32_t)ctl->ng * nseg, ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
+  for (uint32_t t = threadIdx.x; t <= ntiles; t += blockDim.x) {
+    const uint64_t p = min((uint64_t)t * M_EXP_TILE, P - 1);
+    uint32_t l = 0, h = nx;
+    while (h - l > 1) {
+      const uint32_t mid = l + ((h - l) >> 1);
+      if (po[mid] <= p) l = mid; else h = mid;
+    }
+    tile_x[t] = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void m_expand_spec_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                                            const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
+                                                            const uint32_t* __restrict__ g_lo,
+                                                            const shz_seg_dev* __restrict__ segs, uint32_t nseg,
+                                                            const mctl* __restrict__ ctl, uint64_t cap, m_bits mb,
+                                                            uint32_t* __restrict__ v) {
+  const uint64_t P = ctl->P;
+  if (P == 0 || P > cap || (uint64_t)blockIdx.x * M_EXP_TILE >= P) return;   // uniform, before any barrier
+  m_expand_tile<uint32_t>(E, gs, tile_x, po, g_lo, segs, nseg, 0ull, P, mb, (int64_t)0, v);
 }
 
 // ---- fold of the sorted votes into one record per (query, sid) group
@@ -1758,12 +1809,70 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                          (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
       SHZ_HIP(ctx, hipGetLastError());
     }
+    // ONE small query from host memory: its votes are queued now, before their number is known (m_spec_plan_kernel),
+    // through the one-workgroup path below and with that path's conditions; the layout needs the largest query offset,
+    // which the host has
+    static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
+    static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
+    static const bool no_spec = [] { const char* e = getenv("SHZ_MATCH_NO_SPEC"); return e && atoi(e) != 0; }();
+    bool spec = false;
+    uint32_t spec_bias = 0;
+    if (!vs_out && nq == 1 && f_nsh == 1 && m <= MH_MAX && !no_small_head && !no_spec && !(flags & SHZ_IN_DEVICE) &&
+        !(flags_sub & SHZ_MATCH_FULL_SORT) && tiles_env != 0 && force32 != 1 && topn <= VT_MAXTOPN &&
+        (double)m * t->votes_per_hash <= 2.0 * VT_ONE_WG_MAX) {   // (a table whose last query had far more votes: not worth queueing)
+      const uint64_t a0 = query_off[q0], a1 = query_off[q0 + 1];
+      bool wide = false;
+      for (uint64_t i = a0; i < a1; ++i) {
+        spec_bias = std::max(spec_bias, q_off[i]);
+        wide |= q_off[i] >= (1u << QOFF_BITS);
+      }
+      m_bits ms = mb;
+      ms.qb = 0;
+      ms.bias = spec_bias;
+      ms.dbits = bits_for((uint64_t)t->max_off + spec_bias);
+      if (!wide && 31 - ms.sb - ms.dbits >= 0 && ms.dbits <= VT_MAX_DBITS + VT_MAX_DSPLIT) {
+        spec = true;
+        ++ctx->st_spec_queued;
+        const uint64_t cap = VT_ONE_WG_MAX;
+        const uint32_t cap_tiles = (uint32_t)((cap + M_EXP_TILE - 1) / M_EXP_TILE);
+        void *tx, *k32, *ts, *cp, *cd, *cdd;
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, ((uint64_t)cap_tiles + 1) * 4, &tx));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, cap * 8 + 16, &k32));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, 64, &ts));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT1, (uint64_t)topn * 8, &cp));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT2, (uint64_t)topn * 4, &cd));
+        SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT3, (uint64_t)topn * 4, &cdd));
+        uint32_t* n_heavy = (uint32_t*)ts;
+        uint2* heavy = (uint2*)(n_heavy + 2);
+        uint32_t* heavy_q = n_heavy + 4;
+        vt_plan pl;
+        pl.nq = 1;
+        pl.dbits = ms.dbits;
+        pl.sb = ms.sb;
+        pl.g_lo = ms.sb + ms.dbits + 1;   // no bit is ordered: a sweep may split by any song-id bit
+        pl.tile = VW_CHUNK;
+        for (uint32_t i = 0; i <= VT_MAXQ; ++i) { pl.qv[i] = 0u; pl.tb[i] = 0; }   // no tiles, one range (its end: heavy[0])
+        hipLaunchKernelGGL(m_spec_plan_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)po, (const mctl*)d_ctl,
+                           (uint32_t)nseg, cap, (uint32_t*)tx, n_heavy, heavy, heavy_q);
+        hipLaunchKernelGGL(m_expand_spec_kernel, dim3(cap_tiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                           (const uint32_t*)gs, (const uint32_t*)tx, (const uint64_t*)po, (const uint32_t*)glo,
+                           (const shz_seg_dev*)d_segs, (uint32_t)nseg, (const mctl*)d_ctl, cap, ms, (uint32_t*)k32);
+        hipLaunchKernelGGL(vt_fold_kernel, dim3(1), dim3(VT_THREADS), 0, ctx->stream, (const uint32_t*)k32, (const uint2*)heavy,
+                           (const uint32_t*)n_heavy, 1u, pl, topn, (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd,
+                           vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VT_SLOTS, d_vt_err);
+        hipLaunchKernelGGL(vt_rank_kernel, dim3(1), dim3(VR_THREADS), 0, ctx->stream, pl, topn, ms, (const uint64_t*)cp,
+                           (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, 1u,
+                           r_sid, (int32_t*)r_delta, r_al, r_dd, r_n);
+        SHZ_HIP(ctx, hipGetLastError());
+      }
+    }
     // the one read-back before the votes: their number sizes the vote buffers and the sort, their number per query
-    // plans the vote passes
+    // plans the vote passes (behind a queued small query: its results come along)
     void* mailp;
-    SHZ_TRY(shz_mailbox(ctx, 256 + (uint64_t)nq * 8, &mailp));
+    SHZ_TRY(shz_mailbox(ctx, 256 + (uint64_t)nq * 8 + (spec ? rb_bytes : 0), &mailp));
     SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, sizeof(mctl), hipMemcpyDeviceToHost, ctx->stream));
     if (nq > 1) SHZ_HIP(ctx, hipMemcpyAsync((char*)mailp + 256, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (spec) SHZ_HIP(ctx, hipMemcpyAsync((char*)mailp + 256 + 8, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (trace) tr1 = now_s();
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) tr2 = now_s();
@@ -1791,7 +1900,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint32_t ng = (uint32_t)h.ng;
     const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
     const uint64_t P = h.P, rows_total = h.rows;
-    if (mu) ctx->m_votes_per_hash = (double)P / (double)mu;
+    if (mu) ctx->m_votes_per_hash = t->votes_per_hash = (double)P / (double)mu;
     if (P > SUB_BUDGET && nq > 1) {  // too many pairs for one sub-batch: retry with fewer queries
       step = std::max<uint32_t>(1, nq / 2);
       continue;
@@ -1800,7 +1909,10 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     std::vector<uint64_t> h_votes(nq, P);   // votes per query (read back with the counts)
     if (nq > 1) memcpy(h_votes.data(), (const char*)mailp + 256, (uint64_t)nq * 8);
     void* tile_x = nullptr;
-    if (P > 0 && vs_out) {
+    // the queued small query ran when its votes fit (else its kernels did nothing, and the passes below run as ever)
+    const bool spec_done = spec && P <= VT_ONE_WG_MAX && mb.bias == spec_bias;
+    if (spec_done) {
+    } else if (P > 0 && vs_out) {
       // hand the votes over: expand straight into the caller's buffer, in the shared layout, with global query indices
       if (vs_out->count + P <= vs_out->cap) {
         const uint32_t ntiles = (uint32_t)((P + M_EXP_TILE - 1) / M_EXP_TILE);
@@ -1822,10 +1934,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       struct vpass { uint32_t qa, qb; uint64_t v_lo, v_hi; };
       std::vector<vpass> passes;
       const int qbits32 = 31 - mb.sb - mb.dbits;
-      static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
       bool use32 = qbits32 >= 0 && P > MH_MAX && force32 != 0 && !(flags_sub & SHZ_MATCH_FULL_SORT);
       // vote tiles (vt_fold_kernel): two radix passes + an LDS fold per tile instead of four passes + the record chain
-      static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();   // 0 never
       const bool tiles = use32 && tiles_env != 0 && topn <= VT_MAXTOPN && mb.dbits <= VT_MAX_DBITS + VT_MAX_DSPLIT;
       if (use32) {
         const uint32_t q_per_pass = tiles ? (uint32_t)VT_MAXQ : (1u << std::min(qbits32, 30));   // tiles: no query bits in the vote
@@ -1993,10 +2103,16 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     }
     {
       void* hb;
-      SHZ_TRY(shz_mailbox(ctx, rb_bytes, &hb));
-      SHZ_HIP(ctx, hipMemcpyAsync(hb, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
-      if (trace) tr3 = now_s();
-      SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (spec_done) {
+        ++ctx->st_spec_used;
+        hb = (char*)mailp + 256 + 8;   // came with the first read-back
+        if (trace) tr3 = now_s();
+      } else {
+        SHZ_TRY(shz_mailbox(ctx, rb_bytes, &hb));
+        SHZ_HIP(ctx, hipMemcpyAsync(hb, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (trace) tr3 = now_s();
+        SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
       if (trace)
         fprintf(stderr, "match trace: head enqueue %.1f us, wait %.1f us, tail enqueue %.1f us, wait %.1f us (P %llu)\n",
                 (tr1 - tr0) * 1e6, (tr2 - tr1) * 1e6, (tr3 - tr2) * 1e6, (now_s() - tr3) * 1e6, (unsigned long long)P);
@@ -2074,6 +2190,13 @@ extern "C" int32_t shz_set_debug(shz_ctx* ctx, uint32_t flags) {
 extern "C" int32_t shz_match_vt_redo(shz_ctx* ctx, uint64_t* count) {
   if (!ctx || !count) return SHZ_E_INVALID;
   *count = ctx->st_vt_redo;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_match_spec_stats(shz_ctx* ctx, uint64_t* queued, uint64_t* used) {
+  if (!ctx || !queued || !used) return SHZ_E_INVALID;
+  *queued = ctx->st_spec_queued;
+  *used = ctx->st_spec_used;
   return SHZ_OK;
 }
 

@@ -57,6 +57,7 @@ struct shz_table {
   uint64_t st_bytes[3] = {0, 0, 0};                     // sizes of the reserved staging blocks
   std::vector<shz_run> runs;
   int run_sb = 0, run_ob = 0;                           // packing of the runs (0: none yet)
+  double votes_per_hash = 0.0;                          // of the last match against this table (0: none yet): whether a single query's votes are worth queueing ahead of their count
   bool stage_reserved = false;                          // the staging columns were sized by shz_table_reserve: kept
   shz_reserve_job* job = nullptr;
 };
