@@ -1530,12 +1530,14 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_CLIP, (uint64_t)(nc + 1) * 4 + 64, &pc));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)sb.frames * 4 + 64, &ft));
     const stft_args& sa = st[si].sa;
+    static const bool no_small_tail = [] { const char* e = getenv("SHZ_NO_SMALL_TAIL"); return e && atoi(e) != 0; }();
+    const bool small_tail = want_hashes && !no_small_tail && n_words && n_words <= XT_MAX_WORDS && cap_peaks <= XT_MAX_PEAKS;
     if (xp.f32) {
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_UND, (uint64_t)UND_CAP * 8, &d_und));
       if (si) hipLaunchKernelGGL(xctl_begin_sub_kernel, dim3(1), dim3(1), 0, ctx->stream, d_ctl);   // (the block starts zeroed)
       SHZ_HIP(ctx, hipMemsetAsync(d_mask, 0, n_words * 8, ctx->stream));  // peak_pick32 writes non-zero words only
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, (uint64_t)sb.frames * 4 + 64, &d_fcnt));
-      SHZ_HIP(ctx, hipMemsetAsync(d_fcnt, 0, (uint64_t)sb.frames * 4, ctx->stream));
+      if (!small_tail) SHZ_HIP(ctx, hipMemsetAsync(d_fcnt, 0, (uint64_t)sb.frames * 4, ctx->stream));   // (the one-workgroup tail counts from the mask)
       {
         shz_prof_scope ps(ctx, 1);
         p32_args pa;
@@ -1600,8 +1602,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         SHZ_HIP(ctx, hipGetLastError());
       }
     }
-    static const bool no_small_tail = [] { const char* e = getenv("SHZ_NO_SMALL_TAIL"); return e && atoi(e) != 0; }();
-    if (want_hashes && !no_small_tail && n_words && n_words <= XT_MAX_WORDS && cap_peaks <= XT_MAX_PEAKS) {
+    if (small_tail) {
       shz_prof_scope ps(ctx, 3);
       void* d_hoff;
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HOFF, (uint64_t)cap_peaks * 4 + 64, &d_hoff));

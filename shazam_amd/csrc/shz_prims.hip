@@ -84,6 +84,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(In in, T* __re
   if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = (uint64_t)off;
 }
 
+// a few tiles in ONE workgroup that carries the running sum from tile to tile: one launch instead of three where the
+// launches are what a scan costs (the (group x segment) counts of a single query)
+#define SCAN_LOOP_TILES 4
+template <typename T, typename In>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_loop_kernel(In in, T* __restrict__ out, uint64_t n,
+                                                                  uint64_t* __restrict__ total) {
+  __shared__ T lds[8];
+  T carry = 0;
+  for (uint64_t t0 = 0; t0 < n; t0 += SCAN_TILE) {   // uniform
+    const uint64_t base = t0 + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+      v[i] = (base + i < n) ? (T)in(base + i) : (T)0;
+      s += v[i];
+    }
+    T tot;
+    T off = block_excl_scan(s, &tot, lds) + carry;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+      if (base + i < n) out[base + i] = off;
+      off += v[i];
+    }
+    carry += tot;
+  }
+  if (total && threadIdx.x == 0) *total = (uint64_t)carry;
+}
+
 __global__ void set_u64_kernel(uint64_t* p, uint64_t v) { *p = v; }
 
 template <typename T, typename In>
@@ -96,6 +125,11 @@ static int32_t scan_impl(shz_ctx* ctx, In in, T* d_out, uint64_t n, uint64_t* d_
   if (nb == 1) {
     hipLaunchKernelGGL((scan_apply_kernel<T, In>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, d_out,
                        (const T*)nullptr, n, d_total);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
+  }
+  if (nb <= SCAN_LOOP_TILES) {
+    hipLaunchKernelGGL((scan_loop_kernel<T, In>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, d_out, n, d_total);
     SHZ_HIP(ctx, hipGetLastError());
     return SHZ_OK;
   }

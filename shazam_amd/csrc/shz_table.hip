@@ -1183,6 +1183,10 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
     if (gn < nt) { na = ranges[gn].x; nb = ranges[gn].y; }
     const bool checked = b - a > VT_LIMIT2;         // fewer votes than either table may hold: no sweep can overflow
     int cl = 0, ns = 0, nd = 0;                      // candidate list in use; song bits / delta bits the sweeps split by
+    // more votes than table 1 holds keys (a single query's unsorted votes, mostly one per (song, delta)): start with
+    // the sweeps that many distinct pairs need, instead of finding out at the end of a first sweep over everything
+    if (b - a > VT_LIMIT)
+      while (ns < slb && ((uint32_t)VT_LIMIT << ns) < b - a) ++ns;
     bool prefetched = false;
     for (bool done = (a >= b); !done;) {             // until a sweep count is found under which every sweep fits
       bool over = false;
