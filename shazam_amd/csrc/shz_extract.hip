@@ -1445,17 +1445,37 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   struct s2_guard { shz_ctx* c; bool on; ~s2_guard() { if (on && c->stream2) (void)hipStreamSynchronize(c->stream2); } } s2g{ctx, overlap};
   void *p_ctl, *p_offs;
   const uint64_t fb_words = ((uint64_t)n_clips + 31) / 32;   // bitmap of clips that need fp64 staging, behind the control block
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, 256 + fb_words * 4 + 64, &p_ctl));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
+  // A small pass with host outputs keeps everything that is read back in ONE device block, laid out like the mailbox:
+  // control block | clip bitmap | per-clip offsets | entries a | entries b -- one copy at the end instead of four
+  // (a copy is ~5 us of a 120 us call).
+  const uint64_t b_a = want_hashes ? 4 : 2;
+  const bool one_block = !out_dev && !stay && xp.stage_cap <= (1u << 15);
+  const uint64_t ob_offs = 256 + ((fb_words * 4 + 255) & ~255ull);
+  const uint64_t ob_a = ob_offs + (((uint64_t)(n_clips + 1) * 8 + 255) & ~255ull);
+  const uint64_t ob_b = ob_a + ((xp.stage_cap * b_a + 255) & ~255ull);
+  const uint64_t ob_bytes = ob_b + xp.stage_cap * 4;
+  void* p_block = nullptr;
+  if (one_block) {
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, ob_bytes + 64, &p_block));
+    p_ctl = p_block;
+    p_offs = (char*)p_block + ob_offs;
+  } else {
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_CTL, 256 + fb_words * 4 + 64, &p_ctl));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_OFFS, (uint64_t)(n_clips + 1) * 8 + 64, &p_offs));
+  }
   xctl* d_ctl = (xctl*)p_ctl;
   unsigned long long* d_offs = (unsigned long long*)p_offs;
   static_assert(sizeof(xctl) <= 256, "the clip bitmap starts 256 bytes behind the control block");
   uint32_t* d_fb = (uint32_t*)((char*)p_ctl + 256);
-  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, 256 + fb_words * 4, ctx->stream));   // (offs[0] = 0 is written by xctl_offsets_kernel)
+  SHZ_HIP(ctx, hipMemsetAsync(d_ctl, 0, 256 + ((fb_words * 4 + 63) & ~63ull), ctx->stream));   // (whole 64-byte lines: one fill, not a body and a tail)   // (offs[0] = 0 is written by xctl_offsets_kernel)
   // where the entries go: the caller's device arrays, or staging arrays that are copied out after the final sync
   void *o_a = want_hashes ? (void*)key32 : (void*)peak_f, *o_b = want_hashes ? (void*)t1 : (void*)peak_t;
   uint64_t o_cap = cap;
-  if (!out_dev) {
+  if (one_block) {
+    o_cap = xp.stage_cap;
+    o_a = (char*)p_block + ob_a;
+    o_b = (char*)p_block + ob_b;
+  } else if (!out_dev) {
     o_cap = xp.stage_cap;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_KEY, o_cap * 4 + 64, &o_a));
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_T1, o_cap * 4 + 64, &o_b));
@@ -1674,11 +1694,11 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   }
   // The one read-back of the pass, into pinned memory: control block | per-clip offsets | for small host outputs the
   // entries themselves (they ride along instead of costing a second round trip once the count is known).
-  pt->b_a = want_hashes ? 4 : 2;
-  pt->spec = (!out_dev && !stay && o_cap <= (1u << 15)) ? o_cap : 0;
-  pt->off_offs = 256;
-  pt->off_a = pt->off_offs + (((uint64_t)(n_clips + 1) * 8 + 255) & ~255ull);
-  pt->off_b = pt->off_a + ((pt->spec * pt->b_a + 255) & ~255ull);
+  pt->b_a = b_a;
+  pt->spec = one_block ? o_cap : 0;
+  pt->off_offs = one_block ? ob_offs : 256;
+  pt->off_a = one_block ? ob_a : pt->off_offs + (((uint64_t)(n_clips + 1) * 8 + 255) & ~255ull);
+  pt->off_b = one_block ? ob_b : pt->off_a;
   void* mailp;
   SHZ_TRY(shz_mailbox(ctx, pt->off_b + pt->spec * 4, &mailp));
   pt->mp = (char*)mailp;
@@ -1690,11 +1710,11 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   pt->want_hashes = want_hashes;
   pt->stay = stay;
   pt->d_fb = d_fb;
-  SHZ_HIP(ctx, hipMemcpyAsync(pt->mp, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
-  SHZ_HIP(ctx, hipMemcpyAsync(pt->mp + pt->off_offs, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (pt->spec) {
-    SHZ_HIP(ctx, hipMemcpyAsync(pt->mp + pt->off_a, o_a, pt->spec * pt->b_a, hipMemcpyDeviceToHost, ctx->stream));
-    SHZ_HIP(ctx, hipMemcpyAsync(pt->mp + pt->off_b, o_b, pt->spec * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (one_block) {
+    SHZ_HIP(ctx, hipMemcpyAsync(pt->mp, p_block, ob_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    SHZ_HIP(ctx, hipMemcpyAsync(pt->mp, d_ctl, sizeof(xctl), hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(pt->mp + pt->off_offs, d_offs, (uint64_t)(n_clips + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   s2g.on = false;   // the caller's extract_finish synchronises (both streams are joined by the events above)
   return SHZ_OK;

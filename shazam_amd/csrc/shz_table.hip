@@ -517,9 +517,11 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
 // is larger -- the host then sees that count in the one read-back and continues as if nothing had been queued.
 //
 // m_spec_plan_kernel: tile_x of the expand tiles (as m_tile_start_kernel) + the single vote range (as vt_one_range_kernel)
+// + the zeroed result block
 __global__ void m_spec_plan_kernel(const uint64_t* __restrict__ po, const mctl* __restrict__ ctl, uint32_t nseg, uint64_t cap,
                                    uint32_t* __restrict__ tile_x, uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
-                                   uint32_t* __restrict__ heavy_q) {
+                                   uint32_t* __restrict__ heavy_q, uint32_t* __restrict__ rb, uint32_t rb_words) {
+  for (uint32_t i = threadIdx.x; i < rb_words; i += blockDim.x) rb[i] = 0u;   // the result block (the host's fill otherwise)
   const uint64_t P = ctl->P;
   const bool ok = P > 0 && P <= cap;
   if (threadIdx.x == 0) {
@@ -1803,16 +1805,10 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8 + 8;   // + the vote tiles' flag word (and a pad)
     void* rb;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
-    SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));
     uint64_t* d_np = (uint64_t*)rb;
     uint32_t* r_sid = (uint32_t*)(d_np + nq);
     uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
     uint32_t* d_vt_err = d_nh + nq;   // set by a vote-tile kernel whose LDS table or range list overflowed: the sub-batch is voted again by the full sort
-    if (nq > 1) {   // one query: its counts are the totals
-      hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
-                         (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
-      SHZ_HIP(ctx, hipGetLastError());
-    }
     // ONE small query from host memory: its votes are queued now, before their number is known (m_spec_plan_kernel),
     // through the one-workgroup path below and with that path's conditions; the layout needs the largest query offset,
     // which the host has
@@ -1857,7 +1853,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         pl.tile = VW_CHUNK;
         for (uint32_t i = 0; i <= VT_MAXQ; ++i) { pl.qv[i] = 0u; pl.tb[i] = 0; }   // no tiles, one range (its end: heavy[0])
         hipLaunchKernelGGL(m_spec_plan_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)po, (const mctl*)d_ctl,
-                           (uint32_t)nseg, cap, (uint32_t*)tx, n_heavy, heavy, heavy_q);
+                           (uint32_t)nseg, cap, (uint32_t*)tx, n_heavy, heavy, heavy_q, (uint32_t*)rb, (uint32_t)(rb_bytes / 4));
         hipLaunchKernelGGL(m_expand_spec_kernel, dim3(cap_tiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                            (const uint32_t*)gs, (const uint32_t*)tx, (const uint64_t*)po, (const uint32_t*)glo,
                            (const shz_seg_dev*)d_segs, (uint32_t)nseg, (const mctl*)d_ctl, cap, ms, (uint32_t*)k32);
@@ -1869,6 +1865,12 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                            r_sid, (int32_t*)r_delta, r_al, r_dd, r_n);
         SHZ_HIP(ctx, hipGetLastError());
       }
+    }
+    if (!spec) SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));   // (a queued query's first kernel did that)
+    if (nq > 1) {   // one query: its counts are the totals
+      hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
+                         (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
+      SHZ_HIP(ctx, hipGetLastError());
     }
     // the one read-back before the votes: their number sizes the vote buffers and the sort, their number per query
     // plans the vote passes (behind a queued small query: its results come along)
