@@ -171,7 +171,7 @@ int32_t shz_sort_u64(shz_ctx* ctx, uint64_t* k0, uint64_t* k1, void* v0, void* v
 // stable LSD radix sort of 4-byte keys on bits [bit_lo, bit_hi) (k0 <-> k1 ping-pong); the result is written to out64 as
 // 8-byte keys, key + add
 // segments of a segmented 4-byte sort (shz_sort_u32_seg): segment i holds the keys [qv[i], qv[i + 1]) and is cut into
-// the blocks [bq[i], bq[i + 1]) of <= 4,096 keys; no block crosses a segment border
+// the blocks [bq[i], bq[i + 1]) of <= 4,096 or 8,192 keys (bq is filled in by the sort); no block crosses a segment border
 #define SHZ_SEG_MAX 128
 struct shz_seg_plan {
   uint32_t nq;

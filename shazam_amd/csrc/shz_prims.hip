@@ -659,8 +659,8 @@ int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* o
 // per two.  Blocks of <= 4,096 keys never cross a segment border; the digit table is laid out segment-major
 // ([segment][digit][block of the segment]), so ONE linear exclusive scan yields every block's destinations: keys of
 // earlier segments, then smaller digits of the own segment, then the same digit in earlier blocks of the segment.
-__device__ __forceinline__ void seg_of_block(const shz_seg_plan& sp, uint32_t b, uint32_t& seg, uint32_t& lo, uint32_t& len,
-                                             uint32_t& hbase, uint32_t& nbs) {
+__device__ __forceinline__ void seg_of_block(const shz_seg_plan& sp, uint32_t tile, uint32_t b, uint32_t& seg, uint32_t& lo,
+                                             uint32_t& len, uint32_t& hbase, uint32_t& nbs) {
   uint32_t i = 0, hi = sp.nq;                        // last segment with bq[i] <= b (empty segments have no blocks)
   while (hi - i > 1) {
     const uint32_t mid = (i + hi) >> 1;
@@ -668,13 +668,13 @@ __device__ __forceinline__ void seg_of_block(const shz_seg_plan& sp, uint32_t b,
   }
   seg = i;
   const uint32_t bl = b - sp.bq[i];
-  lo = sp.qv[i] + bl * SORT_TILE;
-  len = min((uint32_t)SORT_TILE, sp.qv[i + 1] - lo);
+  lo = sp.qv[i] + bl * tile;
+  len = min(tile, sp.qv[i + 1] - lo);
   nbs = sp.bq[i + 1] - sp.bq[i];
   hbase = bl;                                       // + (bq[i] << BITS) + digit * nbs
 }
 
-template <int BITS>
+template <int BITS, int ROWS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uint32_t* __restrict__ keys, shz_seg_plan sp, int shift,
                                                                         uint32_t dmask, uint32_t* __restrict__ hist) {
   constexpr uint32_t DIG = 1u << BITS;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uin
   for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
   uint32_t seg, lo, len, hb, nbs;
-  seg_of_block(sp, blockIdx.x, seg, lo, len, hb, nbs);
+  seg_of_block(sp, (uint32_t)ROWS * SORT_THREADS, blockIdx.x, seg, lo, len, hb, nbs);
   // a segment starts wherever its query's votes start: up to three keys in front of the first 16-byte boundary and
   // behind the last one are counted singly, the rest four per load
   // (alignment by ADDRESS: the key buffer itself may start anywhere, e.g. the second half of a ping-pong pair)
@@ -691,14 +691,14 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uin
   const uint32_t head = min((4u - mis) & 3u, len), nv = (len - head) >> 2, tail0 = head + 4u * nv;
   {
     const uint4* k4 = (const uint4*)(keys + lo + head);
-    uint4 x[SORT_ROUNDS / 4];
+    uint4 x[ROWS / 4];
 #pragma unroll
-    for (int r = 0; r < SORT_ROUNDS / 4; ++r) {
+    for (int r = 0; r < ROWS / 4; ++r) {
       const uint32_t i = (uint32_t)r * SORT_THREADS + threadIdx.x;
       x[r] = i < nv ? k4[i] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < SORT_ROUNDS / 4; ++r) {
+    for (int r = 0; r < ROWS / 4; ++r) {
       if ((uint32_t)r * SORT_THREADS + threadIdx.x < nv) {
         atomicAdd(&h[(x[r].x >> shift) & dmask], 1u);
         atomicAdd(&h[(x[r].y >> shift) & dmask], 1u);
@@ -715,21 +715,20 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uin
   for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) hist[base + (uint64_t)d * nbs] = h[d];
 }
 
-template <int BITS>
+template <int BITS, int ROWS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ okeys,
                                                                            uint64_t n, shz_seg_plan sp, int shift, uint32_t dmask,
                                                                            const uint32_t* __restrict__ offs, uint64_t n_hist) {
   constexpr uint32_t DIG = 1u << BITS;
   constexpr int DPT = DIG / SORT_THREADS;
-  __shared__ uint32_t skey[SORT_TILE];
+  __shared__ uint32_t skey[ROWS * SORT_THREADS];
   __shared__ uint32_t gbase[DIG];
   __shared__ uint16_t lstart[DIG];
   __shared__ uint16_t wrun[4][DIG];
   __shared__ uint32_t scan_tmp[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t seg, lo, tile_n, hb, nbs;
-  seg_of_block(sp, blockIdx.x, seg, lo, tile_n, hb, nbs);
-  constexpr int ROWS = SORT_TILE / SORT_THREADS;
+  seg_of_block(sp, (uint32_t)ROWS * SORT_THREADS, blockIdx.x, seg, lo, tile_n, hb, nbs);
   uint32_t k[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -807,11 +806,37 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const 
   }
 }
 
-int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp,
+// (the plan's bq is filled in here: the block size is this function's choice)
+template <int ROWS>
+static void seg_pass(shz_ctx* ctx, int wb, uint32_t nblocks, const uint32_t* kin, uint32_t* kout, uint64_t n, const shz_seg_plan& sp,
+                     int shift, uint32_t dmask, uint32_t* hist, uint64_t nh, int32_t* rc) {
+  if (wb == 9) {
+    hipLaunchKernelGGL((sort_hist32_seg_kernel<9, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
+    *rc = shz_scan_u32(ctx, (const uint32_t*)hist, hist, nh, nullptr);
+    if (*rc != SHZ_OK) return;
+    hipLaunchKernelGGL((sort_scatter32_seg_kernel<9, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+  } else {
+    hipLaunchKernelGGL((sort_hist32_seg_kernel<8, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
+    *rc = shz_scan_u32(ctx, (const uint32_t*)hist, hist, nh, nullptr);
+    if (*rc != SHZ_OK) return;
+    hipLaunchKernelGGL((sort_scatter32_seg_kernel<8, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+  }
+}
+
+int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp_in,
                          int* sel) {
   if (sel) *sel = 0;
   if (n == 0 || bit_hi <= bit_lo) return SHZ_OK;
   if (n >= (1ull << 32) || bit_hi > 32) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: n %llu, bits [%d, %d)", (unsigned long long)n, bit_lo, bit_hi);
+  // blocks of 8,192 keys where the segments are long: a block's keys of one digit leave as one run, 128 bytes on average
+  // instead of 64 (the scatter is bound by its partial-line writes)
+  static const int tile_env = [] { const char* e = getenv("SHZ_SEG_TILE"); return e ? atoi(e) : 0; }();
+  const bool big = tile_env ? tile_env >= 8192 : n >= (1ull << 24);   // (fewer than ~2,000 such blocks leave CUs idle: one 10 s query at 1M songs 0.393 -> 0.399 ms)
+  const uint32_t tile = big ? 8192u : 4096u;   // (16,384: 64 keys per thread in registers, 0.185 -> 0.222 ms/query at 1M songs)
+  shz_seg_plan sp = sp_in;
+  sp.bq[0] = 0;
+  for (uint32_t i = 0; i < SHZ_SEG_MAX; ++i)
+    sp.bq[i + 1] = sp.bq[i] + (i < sp.nq ? (sp.qv[i + 1] - sp.qv[i] + tile - 1) / tile : 0u);
   const uint32_t nblocks = sp.bq[sp.nq];
   const int bits = bit_hi - bit_lo;
   const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
@@ -826,15 +851,10 @@ int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, i
     const int wb = w == 9 ? 9 : 8;
     const uint32_t dmask = (1u << std::min(wb, bit_hi - shift)) - 1u;
     const uint64_t nh = (uint64_t)nblocks << wb;
-    if (wb == 9) {
-      hipLaunchKernelGGL(sort_hist32_seg_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, sp, shift, dmask, (uint32_t*)hist);
-      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, nh, nullptr));
-      hipLaunchKernelGGL(sort_scatter32_seg_kernel<9>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
-    } else {
-      hipLaunchKernelGGL(sort_hist32_seg_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, sp, shift, dmask, (uint32_t*)hist);
-      SHZ_TRY(shz_scan_u32(ctx, (const uint32_t*)hist, (uint32_t*)hist, nh, nullptr));
-      hipLaunchKernelGGL(sort_scatter32_seg_kernel<8>, dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, (const uint32_t*)kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
-    }
+    int32_t rc = SHZ_OK;
+    if (big) seg_pass<32>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, &rc);
+    else seg_pass<16>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, &rc);
+    SHZ_TRY(rc);
     SHZ_HIP(ctx, hipGetLastError());
     shift += wb;
     std::swap(kin, kout);

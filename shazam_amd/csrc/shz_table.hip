@@ -991,6 +991,7 @@ struct vt_plan {
   int g_lo;                    // lowest bit the radix passes ordered: tiles are cut where bits >= g_lo change
   int dbits, sb;               // layout of a vote: flag | delta (dbits) | song id (sb) | query
   uint32_t tile;               // nominal votes per tile
+  uint32_t flush;              // votes a batch of vt_stream_kernel holds before it may end at a group border
 };
 
 __device__ __forceinline__ uint32_t vt_query_of_tile(const vt_plan& pl, uint32_t g) {
@@ -1336,7 +1337,7 @@ __global__ __launch_bounds__(VT_THREADS) void vt_fold_kernel(const uint32_t* __r
 static_assert(VW_LIMIT1 + 64 < VW_S1, "a probe must find a free slot");
 static_assert(VW_FLUSH + 64 <= VT_TILE, "a range handed to vt_fold_kernel has less than VT_TILE votes before its last group");
 
-template <int VW_B2>
+template <int VW_B2, bool QR = true>
 __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restrict__ k, const uint32_t* __restrict__ tile_start,
                                                        vt_plan pl, uint32_t topn, uint64_t* __restrict__ c_pack,
                                                        uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
@@ -1397,6 +1398,19 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
           const uint32_t s = lane + 64 * u, kk = key2[s];
           pk[u] = kk == VT_EMPTY ? 0ull : ((best[s] >> 32) << 32) | (0xFFFFFFFFu - (kk & smask));
         }
+        // the usual batch changes nothing: its best song ranks below the n-th candidate (noise votes count 1 each, and
+        // the votes arrive by ascending song id, so among equal counts the earlier batches win) -- one maximum says so
+        // (a song lies in one group, hence in one batch: the candidates are other songs, packs are unique)
+        if (QR) {
+          uint64_t bm = pk[0];
+#pragma unroll
+          for (int u = 1; u < CE; ++u) bm = pk[u] > bm ? pk[u] : bm;
+          const uint32_t bh = vt_wave_max((uint32_t)(bm >> 32));
+          const uint32_t bl = vt_wave_max((uint32_t)(bm >> 32) == bh ? (uint32_t)bm : 0u);
+          const uint32_t nth_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cp >> 32), (int)topn - 1);
+          const uint32_t nth_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cp, (int)topn - 1);
+          if ((((uint64_t)bh << 32) | bl) < (((uint64_t)nth_hi << 32) | nth_lo)) { clear(); n1 = n2 = 0; return; }
+        }
         uint64_t prev = ~0ull, ncp = 0;
         uint32_t ncdl = 0, ncdd = 0;
         for (uint32_t n = 0; n < topn; ++n) {
@@ -1454,7 +1468,7 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
           continue;
         }
         uint32_t cut = 64;                           // the batch may end at the next group border once it is large enough
-        if (batch_votes >= VW_FLUSH && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
+        if (batch_votes >= pl.flush && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
         if (cut == lo) { flush(); batch_start = base + lo; batch_votes = 0; continue; }
         insert(valid && lane >= lo && lane < cut, v);
         const bool over = n1 > VW_LIMIT1 || n2 > VW_LIMIT2;
@@ -1851,6 +1865,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         pl.sb = ms.sb;
         pl.g_lo = ms.sb + ms.dbits + 1;   // no bit is ordered: a sweep may split by any song-id bit
         pl.tile = VW_CHUNK;
+        pl.flush = VW_FLUSH;
         for (uint32_t i = 0; i <= VT_MAXQ; ++i) { pl.qv[i] = 0u; pl.tb[i] = 0; }   // no tiles, one range (its end: heavy[0])
         hipLaunchKernelGGL(m_spec_plan_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)po, (const mctl*)d_ctl,
                            (uint32_t)nseg, cap, (uint32_t*)tx, n_heavy, heavy, heavy_q, (uint32_t*)rb, (uint32_t)(rb_bytes / 4));
@@ -2013,6 +2028,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
           pl.sb = mbp.sb;
           pl.g_lo = mbp.sb + mbp.dbits + 1;   // no bit is ordered: a sweep may split by any song-id bit
           pl.tile = VW_CHUNK;
+          pl.flush = VW_FLUSH;
           for (uint32_t i = 0; i <= VT_MAXQ; ++i) { pl.qv[i] = i ? (uint32_t)pp : 0u; pl.tb[i] = 0; }   // no tiles, one range
           void *ts, *cp, *cd, *cdd;
           SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, 64, &ts));
@@ -2047,6 +2063,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
             pl.sb = mbp.sb;
             pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
             pl.tile = VW_CHUNK;
+            static const uint32_t flush_env = [] { const char* e = getenv("SHZ_VW_FLUSH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : 0u; }();
+            pl.flush = flush_env ? flush_env : VW_FLUSH;
             pl.qv[0] = pl.tb[0] = sp.qv[0] = sp.bq[0] = 0;
             for (uint32_t i = 0; i < nqp; ++i) {
               const uint64_t c = nq > 1 ? h_votes[vp.qa + i] : pp;
@@ -2078,7 +2096,12 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
             // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
             const int slb_ = pl.g_lo - 1 - mbp.dbits;
             const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(t->max_sid, 1u));
-            if ((double)(1u << slb_) + 64.0 / per_song <= 40.0)
+            static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
+            if (no_qr)
+              hipLaunchKernelGGL((vt_stream_kernel<7, false>), dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+            else if ((double)(1u << slb_) + (double)pl.flush / per_song <= 40.0)
               hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
                                  (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
                                  vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
