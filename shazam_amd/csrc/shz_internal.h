@@ -73,6 +73,7 @@ enum {
   SHZ_WS_M8, SHZ_WS_M9,      // top-n candidates of the vote fold (M3 / M4 hold the probe's group tables until the last vote pass)
   SHZ_WS_VT0, SHZ_WS_VT1, SHZ_WS_VT2, SHZ_WS_VT3,   // vote tiles: tile starts, candidate records
   SHZ_WS_VT4,        // table of the vote passes
+  SHZ_WS_VT5,        // sub-group of every expand chunk's first vote (expand by sort blocks)
   SHZ_WS_COUNT
 };
 
@@ -179,7 +180,10 @@ struct shz_seg_plan {
   uint32_t bq[SHZ_SEG_MAX + 1];
 };
 int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp,
-                         int* sel);
+                         int* sel, bool hist0 = false);
+uint32_t shz_seg_tile(uint64_t n);                          // keys per block the sort of n keys uses
+void shz_seg_blocks(shz_seg_plan* sp, uint32_t tile);       // bq from nq, qv
+int shz_seg_first_pass(int bit_lo, int bit_hi, uint32_t* dmask);   // digit width (8 or 9) and mask of the first pass
 int32_t shz_sort_u32_widen(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t* out64, uint64_t n, int bit_lo, int bit_hi,
                            uint64_t add, int* sel);
 

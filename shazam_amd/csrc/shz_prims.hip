@@ -715,48 +715,64 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist32_seg_kernel(const uin
   for (uint32_t d = threadIdx.x; d < DIG; d += SORT_THREADS) hist[base + (uint64_t)d * nbs] = h[d];
 }
 
-template <int BITS, int ROWS>
-__global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ okeys,
-                                                                           uint64_t n, shz_seg_plan sp, int shift, uint32_t dmask,
-                                                                           const uint32_t* __restrict__ offs, uint64_t n_hist) {
-  constexpr uint32_t DIG = 1u << BITS;
-  constexpr int DPT = DIG / SORT_THREADS;
-  __shared__ uint32_t skey[ROWS * SORT_THREADS];
+// NW waves per workgroup, ROWS keys per thread: a block of 64 * NW * ROWS keys.  (8,192 keys as 8 waves x 16 rows instead
+// of 4 x 32 -- twice the waves per CU for the same runs: 0.1765 -> 0.1785 ms/query at 1M songs, same box; not used.)
+template <int BITS, int ROWS, int NW>
+__global__ __launch_bounds__(64 * NW) void sort_scatter32_seg_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ okeys,
+                                                                      uint64_t n, shz_seg_plan sp, int shift, uint32_t dmask,
+                                                                      const uint32_t* __restrict__ offs, uint64_t n_hist) {
+  constexpr uint32_t DIG = 1u << BITS, THREADS = 64u * NW;
+  constexpr int DPT = DIG >= THREADS ? DIG / THREADS : 1;   // digits a thread owns (threads past the last digit: none)
+  __shared__ uint32_t skey[ROWS * THREADS];
   __shared__ uint32_t gbase[DIG];
   __shared__ uint16_t lstart[DIG];
-  __shared__ uint16_t wrun[4][DIG];
-  __shared__ uint32_t scan_tmp[8];
+  __shared__ uint16_t wrun[NW][DIG];
+  __shared__ uint32_t scan_tmp[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool owner = threadIdx.x * DPT < DIG;
   uint32_t seg, lo, tile_n, hb, nbs;
-  seg_of_block(sp, (uint32_t)ROWS * SORT_THREADS, blockIdx.x, seg, lo, tile_n, hb, nbs);
+  seg_of_block(sp, (uint32_t)ROWS * THREADS, blockIdx.x, seg, lo, tile_n, hb, nbs);
   uint32_t k[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     k[r] = li < tile_n ? keys[lo + li] : 0;
   }
+  if (owner) {
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) wrun[w][threadIdx.x * DPT + i] = 0;
+      for (int i = 0; i < DPT; ++i) wrun[w][threadIdx.x * DPT + i] = 0;
+  }
   {
     uint32_t g0[DPT], c[DPT], sum = 0;
     const uint64_t base = ((uint64_t)sp.bq[seg] << BITS) + hb;
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
-      const uint64_t f = base + (uint64_t)(threadIdx.x * DPT + i) * nbs;
-      g0[i] = offs[f];
-      const uint32_t g1 = (f + 1 < n_hist) ? offs[f + 1] : (uint32_t)n;   // the next entry of the scan: own count behind g0
-      c[i] = g1 - g0[i];
-      sum += c[i];
+      g0[i] = c[i] = 0;
+      if (owner) {
+        const uint64_t f = base + (uint64_t)(threadIdx.x * DPT + i) * nbs;
+        g0[i] = offs[f];
+        const uint32_t g1 = (f + 1 < n_hist) ? offs[f + 1] : (uint32_t)n;   // the next entry of the scan: own count behind g0
+        c[i] = g1 - g0[i];
+        sum += c[i];
+      }
     }
-    uint32_t tot;
-    uint32_t ls = block_excl_scan<uint32_t>(sum, &tot, scan_tmp);
+    // exclusive scan of `sum` over the workgroup
+    const uint32_t inc = wave_incl_scan(sum, lane);
+    if (lane == 63) scan_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t ls = inc - sum;
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) {
-      gbase[threadIdx.x * DPT + i] = g0[i];
-      lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
-      ls += c[i];
+    for (int w = 0; w < NW; ++w)
+      if (w < wave) ls += scan_tmp[w];
+    if (owner) {
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        gbase[threadIdx.x * DPT + i] = g0[i];
+        lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
+        ls += c[i];
+      }
     }
   }
   __syncthreads();
@@ -779,15 +795,18 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const 
     if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
   }
   __syncthreads();
+  if (owner) {
 #pragma unroll
-  for (int i = 0; i < DPT; ++i) {
-    const uint32_t d = threadIdx.x * DPT + i;
-    const uint32_t c0 = wrun[0][d], c1 = wrun[1][d], c2 = wrun[2][d];
-    const uint32_t ls = lstart[d];
-    wrun[0][d] = (uint16_t)ls;
-    wrun[1][d] = (uint16_t)(ls + c0);
-    wrun[2][d] = (uint16_t)(ls + c0 + c1);
-    wrun[3][d] = (uint16_t)(ls + c0 + c1 + c2);
+    for (int i = 0; i < DPT; ++i) {
+      const uint32_t d = threadIdx.x * DPT + i;
+      uint32_t at = lstart[d];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t cw = wrun[w][d];
+        wrun[w][d] = (uint16_t)at;
+        at += cw;
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -799,51 +818,77 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_seg_kernel(const 
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_THREADS) {
+  for (uint32_t i = threadIdx.x; i < tile_n; i += THREADS) {
     const uint32_t kk = skey[i];
     const uint32_t d = (kk >> shift) & dmask;
     okeys[gbase[d] + (i - lstart[d])] = kk;
   }
 }
 
-// (the plan's bq is filled in here: the block size is this function's choice)
-template <int ROWS>
+// HR: keys per thread of the counting kernel (256 threads); the scatter covers the same block as NW waves x SR rows
+template <int HR, int SR, int NW>
 static void seg_pass(shz_ctx* ctx, int wb, uint32_t nblocks, const uint32_t* kin, uint32_t* kout, uint64_t n, const shz_seg_plan& sp,
-                     int shift, uint32_t dmask, uint32_t* hist, uint64_t nh, int32_t* rc) {
+                     int shift, uint32_t dmask, uint32_t* hist, uint64_t nh, bool counted, int32_t* rc) {
+  static_assert(HR * SORT_THREADS == SR * 64 * NW, "one block size");
   if (wb == 9) {
-    hipLaunchKernelGGL((sort_hist32_seg_kernel<9, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
+    if (!counted) hipLaunchKernelGGL((sort_hist32_seg_kernel<9, HR>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
     *rc = shz_scan_u32(ctx, (const uint32_t*)hist, hist, nh, nullptr);
     if (*rc != SHZ_OK) return;
-    hipLaunchKernelGGL((sort_scatter32_seg_kernel<9, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+    hipLaunchKernelGGL((sort_scatter32_seg_kernel<9, SR, NW>), dim3(nblocks), dim3(64 * NW), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
   } else {
-    hipLaunchKernelGGL((sort_hist32_seg_kernel<8, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
+    if (!counted) hipLaunchKernelGGL((sort_hist32_seg_kernel<8, HR>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, sp, shift, dmask, hist);
     *rc = shz_scan_u32(ctx, (const uint32_t*)hist, hist, nh, nullptr);
     if (*rc != SHZ_OK) return;
-    hipLaunchKernelGGL((sort_scatter32_seg_kernel<8, ROWS>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
+    hipLaunchKernelGGL((sort_scatter32_seg_kernel<8, SR, NW>), dim3(nblocks), dim3(64 * NW), 0, ctx->stream, kin, kout, n, sp, shift, dmask, (const uint32_t*)hist, nh);
   }
 }
 
+// keys per block of a segmented sort of n keys: blocks of 8,192 keys where the segments are long: a block's keys of one
+// digit leave as one run, 128 bytes on average instead of 64 (the scatter is bound by its partial-line writes)
+// (16,384: 64 keys per thread in registers, 0.185 -> 0.222 ms/query at 1M songs)
+uint32_t shz_seg_tile(uint64_t n) {
+  static const int tile_env = [] { const char* e = getenv("SHZ_SEG_TILE"); return e ? atoi(e) : 0; }();
+  // (fewer than ~2,000 large blocks leave CUs idle: one 10 s query at 1M songs 0.393 -> 0.399 ms)
+  const bool big = tile_env ? tile_env >= 8192 : n >= (1ull << 24);
+  return big ? 8192u : 4096u;
+}
+
+void shz_seg_blocks(shz_seg_plan* sp, uint32_t tile) {
+  sp->bq[0] = 0;
+  for (uint32_t i = 0; i < SHZ_SEG_MAX; ++i)
+    sp->bq[i + 1] = sp->bq[i] + (i < sp->nq ? (sp->qv[i + 1] - sp->qv[i] + tile - 1) / tile : 0u);
+}
+
+// width of the first pass over the bits [bit_lo, bit_hi), and the digit mask of that pass
+int shz_seg_first_pass(int bit_lo, int bit_hi, uint32_t* dmask) {
+  const int bits = bit_hi - bit_lo;
+  const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
+  const bool wide = np9 < np8;
+  const int wb = wide ? 9 : 8;   // (a plan with a 9-bit pass is not counted ahead: its table has 512 columns per block)
+  if (dmask) *dmask = (1u << std::min(wb, bits)) - 1u;
+  return wb;
+}
+
+// `hist0`: the digit table of the FIRST pass is already in the SHZ_WS_SORT_H workspace (the producer of the keys counted
+// them, block by block, in this function's layout -- m_expand_blocks_kernel); sp_in then carries the blocks (shz_seg_blocks
+// with shz_seg_tile(n)) the producer used
 int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, int bit_lo, int bit_hi, const shz_seg_plan& sp_in,
-                         int* sel) {
+                         int* sel, bool hist0) {
   if (sel) *sel = 0;
   if (n == 0 || bit_hi <= bit_lo) return SHZ_OK;
   if (n >= (1ull << 32) || bit_hi > 32) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: n %llu, bits [%d, %d)", (unsigned long long)n, bit_lo, bit_hi);
-  // blocks of 8,192 keys where the segments are long: a block's keys of one digit leave as one run, 128 bytes on average
-  // instead of 64 (the scatter is bound by its partial-line writes)
-  static const int tile_env = [] { const char* e = getenv("SHZ_SEG_TILE"); return e ? atoi(e) : 0; }();
-  const bool big = tile_env ? tile_env >= 8192 : n >= (1ull << 24);   // (fewer than ~2,000 such blocks leave CUs idle: one 10 s query at 1M songs 0.393 -> 0.399 ms)
-  const uint32_t tile = big ? 8192u : 4096u;   // (16,384: 64 keys per thread in registers, 0.185 -> 0.222 ms/query at 1M songs)
+  const uint32_t tile = shz_seg_tile(n);
+  const bool big = tile == 8192u;
   shz_seg_plan sp = sp_in;
-  sp.bq[0] = 0;
-  for (uint32_t i = 0; i < SHZ_SEG_MAX; ++i)
-    sp.bq[i + 1] = sp.bq[i] + (i < sp.nq ? (sp.qv[i + 1] - sp.qv[i] + tile - 1) / tile : 0u);
+  shz_seg_blocks(&sp, tile);
   const uint32_t nblocks = sp.bq[sp.nq];
   const int bits = bit_hi - bit_lo;
   const int np8 = (bits + 7) / 8, np9 = (bits + 8) / 9;
   const bool wide = np9 < np8;
+  if (hist0 && wide) SHZ_FAIL(ctx, SHZ_E_INVALID, "sort32: a counted first pass is 8 bits wide");
   void* hist;
   const uint64_t n_hist = (uint64_t)nblocks << (wide ? 9 : 8);
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, n_hist * 4, &hist));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, n_hist * 4, &hist));   // (same size as the producer's reservation: same block)
   uint32_t *kin = k0, *kout = k1;
   int left = wide ? np9 : np8;
   for (int shift = bit_lo; shift < bit_hi; --left) {
@@ -852,8 +897,9 @@ int32_t shz_sort_u32_seg(shz_ctx* ctx, uint32_t* k0, uint32_t* k1, uint64_t n, i
     const uint32_t dmask = (1u << std::min(wb, bit_hi - shift)) - 1u;
     const uint64_t nh = (uint64_t)nblocks << wb;
     int32_t rc = SHZ_OK;
-    if (big) seg_pass<32>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, &rc);
-    else seg_pass<16>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, &rc);
+    const bool counted = hist0 && shift == bit_lo;
+    if (big) seg_pass<32, 32, 4>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, counted, &rc);
+    else seg_pass<16, 16, 4>(ctx, wb, nblocks, kin, kout, n, sp, shift, dmask, (uint32_t*)hist, nh, counted, &rc);
     SHZ_TRY(rc);
     SHZ_HIP(ctx, hipGetLastError());
     shift += wb;
@@ -886,7 +932,7 @@ extern "C" int32_t shz_sort_keys32_seg(shz_ctx* ctx, const uint32_t* keys, const
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_A, (n4 + n) * 4, &k0));
   SHZ_HIP(ctx, shz_memcpy(ctx, k0, keys, n * 4, hipMemcpyHostToDevice));
   int sel = 0;
-  SHZ_TRY(shz_sort_u32_seg(ctx, (uint32_t*)k0, (uint32_t*)k0 + n4, n, (int)bit_lo, (int)bit_hi, sp, &sel));
+  SHZ_TRY(shz_sort_u32_seg(ctx, (uint32_t*)k0, (uint32_t*)k0 + n4, n, (int)bit_lo, (int)bit_hi, sp, &sel, false));
   SHZ_HIP(ctx, shz_memcpy(ctx, out, (uint32_t*)k0 + (sel ? n4 : 0), n * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHZ_OK;

@@ -418,24 +418,26 @@ __device__ __forceinline__ uint64_t m_vote(uint64_t e, uint32_t sid, uint32_t of
 
 // Votes [v_lo, P) of the sub-batch go to v[0 ..): VT = uint64_t, or uint32_t when a pass's queries, song ids and deltas
 // fit 31 bits (q_base then shifts the query index to the pass's first query).
-template <typename VT>
-__device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
-                                              const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
-                                              const uint32_t* __restrict__ g_lo,
-                                              const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
-                                              uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
+// The votes [base, end) of the sub-batch, whose sub-groups are [xA, xB], go to v[base - v_lo ..).  HIST: the digit
+// (vote >> shift) & dmask of every vote is counted in h (LDS, 256 counters of the caller).  May be called in a loop: the
+// tables below are rewritten per call, behind a barrier.
+template <typename VT, bool HIST>
+__device__ __forceinline__ void m_expand_chunk(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                               const uint64_t* __restrict__ po, const uint32_t* __restrict__ g_lo,
+                                               const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                               uint64_t base, uint64_t end, uint32_t xA, uint32_t xB, m_bits mb,
+                                               int64_t q_base, VT* __restrict__ v, uint32_t* h, int shift, uint32_t dmask) {
   __shared__ uint64_t s_po[M_EXP_SUB], s_e[M_EXP_SUB];
   __shared__ uint32_t s_lo[M_EXP_SUB], s_e0[M_EXP_SUB], s_noff[M_EXP_SUB], s_sg[M_EXP_SUB];
   __shared__ const uint32_t* s_sid[SHZ_MAX_SEGS];
   __shared__ const uint32_t* s_off[SHZ_MAX_SEGS];
-  const uint64_t base = v_lo + (uint64_t)blockIdx.x * M_EXP_TILE;
-  const uint64_t last = min(base + M_EXP_TILE, P) - 1;
-  const uint32_t xA = tile_x[blockIdx.x], xB = tile_x[blockIdx.x + 1];  // sub-groups of the tile's pairs: [xA, xB]
+  if (HIST) __syncthreads();   // (the previous chunk's tables are still being read)
+  const uint64_t last = end - 1;
   const uint32_t cnt = xB - xA + 1;
   int iters = 0;
   while ((1u << iters) < cnt) ++iters;  // uniform
   uint64_t p[M_EXP_PER];
-  uint32_t l[M_EXP_PER], h[M_EXP_PER];
+  uint32_t l[M_EXP_PER], hh[M_EXP_PER];
 #pragma unroll
   for (int j = 0; j < M_EXP_PER; ++j)
     p[j] = min(base + (uint64_t)j * 256 + threadIdx.x, last);  // clamped: lanes past the end redo the last pair, unstored
@@ -453,12 +455,12 @@ __device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, co
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < M_EXP_PER; ++j) { l[j] = 0; h[j] = cnt; }  // last i in [0, cnt) with s_po[i] <= p
+    for (int j = 0; j < M_EXP_PER; ++j) { l[j] = 0; hh[j] = cnt; }  // last i in [0, cnt) with s_po[i] <= p
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int j = 0; j < M_EXP_PER; ++j) {
-        const uint32_t mid = (l[j] + h[j]) >> 1;   // == l once h - l <= 1: s_po[l] <= p keeps l
-        if (s_po[mid] <= p[j]) l[j] = mid; else h[j] = mid;
+        const uint32_t mid = (l[j] + hh[j]) >> 1;   // == l once h - l <= 1: s_po[l] <= p keeps l
+        if (s_po[mid] <= p[j]) l[j] = mid; else hh[j] = mid;
       }
     }
 #pragma unroll
@@ -472,18 +474,21 @@ __device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, co
       const uint32_t row = s_lo[i] + ridx, sg = s_sg[i];
       const uint64_t out = m_vote(e, s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
       const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
-      if (pj < P) v[pj - v_lo] = (VT)out;
+      if (pj < end) {
+        v[pj - v_lo] = (VT)out;
+        if (HIST) atomicAdd(&h[((uint32_t)out >> shift) & dmask], 1u);
+      }
     }
     return;
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < M_EXP_PER; ++j) { l[j] = xA; h[j] = xB + 1; }  // last x in [xA, xB] with po[x] <= p
+  for (int j = 0; j < M_EXP_PER; ++j) { l[j] = xA; hh[j] = xB + 1; }  // last x in [xA, xB] with po[x] <= p
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < M_EXP_PER; ++j) {
-      const uint32_t mid = (l[j] + h[j]) >> 1;
-      if (po[mid] <= p[j]) l[j] = mid; else h[j] = mid;
+      const uint32_t mid = (l[j] + hh[j]) >> 1;
+      if (po[mid] <= p[j]) l[j] = mid; else hh[j] = mid;
     }
   }
 #pragma unroll 2
@@ -496,8 +501,23 @@ __device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, co
     const uint32_t row = g_lo[x] + ridx;
     const uint64_t out = m_vote(E[e0 + oi], s_sid[sg][row], s_off[sg][row], oi == 0 ? 1u : 0u, mb, q_base);
     const uint64_t pj = base + (uint64_t)j * 256 + threadIdx.x;
-    if (pj < P) v[pj - v_lo] = (VT)out;
+    if (pj < end) {
+      v[pj - v_lo] = (VT)out;
+      if (HIST) atomicAdd(&h[((uint32_t)out >> shift) & dmask], 1u);
+    }
   }
+}
+
+// one tile of M_EXP_TILE votes per workgroup
+template <typename VT>
+__device__ __forceinline__ void m_expand_tile(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                              const uint32_t* __restrict__ tile_x, const uint64_t* __restrict__ po,
+                                              const uint32_t* __restrict__ g_lo,
+                                              const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                              uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
+  const uint64_t base = v_lo + (uint64_t)blockIdx.x * M_EXP_TILE;
+  m_expand_chunk<VT, false>(E, gs, po, g_lo, segs, nseg, v_lo, base, min(base + M_EXP_TILE, P), tile_x[blockIdx.x],
+                            tile_x[blockIdx.x + 1], mb, q_base, v, nullptr, 0, 0u);
 }
 
 template <typename VT>
@@ -507,6 +527,64 @@ __global__ __launch_bounds__(256) void m_expand_kernel(const uint64_t* __restric
                                                        const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
                                                        uint64_t P, m_bits mb, int64_t q_base, VT* __restrict__ v) {
   m_expand_tile<VT>(E, gs, tile_x, po, g_lo, segs, nseg, v_lo, P, mb, q_base, v);
+}
+
+// ---- expand by the BLOCKS of the segmented vote sort (shz_sort_u32_seg): workgroup b produces the votes of sort block b
+// (<= 4,096 or 8,192 votes of one query, M_EXP_TILE at a time) and counts their first-pass digits on the way, in the
+// sort's table layout -- the sort's first counting kernel (a pass over all votes at 3.4 TB/s, 5 % of a match at 1M songs)
+// is not run.  cx[b * (cpb + 1) + c], c = 0 .. cpb: the sub-group of the first vote of chunk c of block b (cpb chunks of
+// M_EXP_TILE votes per block; positions past the block's end name its end).
+__device__ __forceinline__ void m_block_range(const shz_seg_plan& sp, uint32_t tile, uint32_t b, uint32_t& seg, uint32_t& bl,
+                                              uint32_t& bs, uint32_t& be) {
+  uint32_t i = 0, hi = sp.nq;                        // last segment with bq[i] <= b (empty segments have no blocks)
+  while (hi - i > 1) {
+    const uint32_t mid = (i + hi) >> 1;
+    if (sp.bq[mid] <= b) i = mid; else hi = mid;
+  }
+  seg = i;
+  bl = b - sp.bq[i];
+  bs = sp.qv[i] + bl * tile;
+  be = min(bs + tile, sp.qv[i + 1]);
+}
+
+__global__ void m_chunk_start_kernel(const uint64_t* __restrict__ po, uint32_t nx, shz_seg_plan sp, uint32_t tile, uint64_t v_lo,
+                                     uint64_t v_hi, uint32_t* __restrict__ cx) {
+  const uint32_t cpb = tile / M_EXP_TILE, nb = sp.bq[sp.nq];
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nb * (cpb + 1)) return;
+  const uint32_t b = e / (cpb + 1), c = e - b * (cpb + 1);
+  uint32_t seg, bl, bs, be;
+  m_block_range(sp, tile, b, seg, bl, bs, be);
+  const uint64_t p = min(v_lo + min(bs + c * M_EXP_TILE, be), v_hi - 1);
+  uint32_t l = 0, h = nx;
+  while (h - l > 1) {
+    const uint32_t mid = l + ((h - l) >> 1);
+    if (po[mid] <= p) l = mid; else h = mid;
+  }
+  cx[e] = l;
+}
+
+__global__ __launch_bounds__(256) void m_expand_blocks_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+                                                              const uint32_t* __restrict__ cx, const uint64_t* __restrict__ po,
+                                                              const uint32_t* __restrict__ g_lo,
+                                                              const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
+                                                              shz_seg_plan sp, uint32_t tile, m_bits mb, int shift, uint32_t dmask,
+                                                              uint32_t* __restrict__ v, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;   // (every chunk starts with a barrier)
+  const uint32_t cpb = tile / M_EXP_TILE;
+  uint32_t seg, bl, bs, be;
+  m_block_range(sp, tile, blockIdx.x, seg, bl, bs, be);
+  const uint32_t* cxb = cx + (uint64_t)blockIdx.x * (cpb + 1);
+  for (uint32_t c = 0; c < cpb; ++c) {   // uniform
+    const uint32_t cb = bs + c * M_EXP_TILE;
+    if (cb >= be) break;
+    m_expand_chunk<uint32_t, true>(E, gs, po, g_lo, segs, nseg, v_lo, v_lo + cb, v_lo + min(cb + (uint32_t)M_EXP_TILE, be), cxb[c],
+                                   cxb[c + 1], mb, M_NO_QUERY_BITS, v, h, shift, dmask);
+  }
+  __syncthreads();
+  const uint32_t nbs = sp.bq[seg + 1] - sp.bq[seg];
+  hist[((uint64_t)sp.bq[seg] << 8) + bl + (uint64_t)threadIdx.x * nbs] = h[threadIdx.x];
 }
 
 // ---- one small query, votes queued BEFORE their number is known on the host
@@ -1983,6 +2061,12 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       const uint64_t pmax4 = (pmax + 3) & ~3ull;   // second 4-byte vote buffer of a pass: 16-byte aligned behind the first
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, pmax * 8 + 16, &v0));
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_D, pmax * 8, &v1));
+      // vote tiles: the expand runs by the blocks of the segmented sort and counts the first pass's digits (no tile starts
+      // here: m_chunk_start_kernel per pass)
+      static const bool no_fuse = [] { const char* e = getenv("SHZ_NO_EXPAND_HIST"); return e && atoi(e) != 0; }();
+      const int Bt_all = mb.sb + mb.dbits + 1, g_lo_all = std::max(1 + mb.dbits, Bt_all - VT_ORDERED_BITS);
+      uint32_t fuse_dmask = 0;
+      const bool fuse = tiles && use32 && !no_fuse && shz_seg_first_pass(g_lo_all, Bt_all, &fuse_dmask) == 8;
       // the sub-group of every expand tile's first pair, for all passes in one launch: pass table (votes, first entry)
       // up, one kernel
       std::vector<uint32_t> toff(passes.size() + 1, 0);
@@ -1994,7 +2078,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
       }
       memcpy(ptab.data() + passes.size() * 2, toff.data(), toff.size() * 4);
       SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_HCNT, (uint64_t)toff.back() * 4, &tile_x));   // (M5 belongs to the fold)
-      if (passes.size() == 1) {   // no table to send up
+      if (fuse) {
+      } else if (passes.size() == 1) {   // no table to send up
         hipLaunchKernelGGL(m_tile_start_kernel, dim3(nblk(toff.back())), dim3(256), 0, ctx->stream, (const uint64_t*)po, (uint32_t)nx,
                            passes[0].v_lo, passes[0].v_hi, toff.back() - 1, (uint32_t*)tile_x);
       } else {
@@ -2048,11 +2133,13 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
           SHZ_HIP(ctx, hipGetLastError());
         } else if (use32) {
           uint32_t* k32 = (uint32_t*)v0;   // two 4-byte buffers in SORT_C, the widened result in SORT_D
-          hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
-                             (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
-                             (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp,
-                             tiles ? M_NO_QUERY_BITS : -(int64_t)vp.qa, k32);
-          SHZ_HIP(ctx, hipGetLastError());
+          if (!fuse) {
+            hipLaunchKernelGGL(m_expand_kernel<uint32_t>, dim3(ntiles), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                               (const uint32_t*)gs, (const uint32_t*)tile_x, (const uint64_t*)po, (const uint32_t*)glo,
+                               (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, vp.v_hi, mbp,
+                               tiles ? M_NO_QUERY_BITS : -(int64_t)vp.qa, k32);
+            SHZ_HIP(ctx, hipGetLastError());
+          }
           const int B = mbp.qb + mbp.sb + mbp.dbits + 1;
           if (tiles) {
             vt_plan pl;
@@ -2078,8 +2165,23 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
               sp.bq[i + 1] = sp.bq[nqp];
             }
             const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
+            if (fuse) {
+              const uint32_t stile = shz_seg_tile(pp), cpb = stile / M_EXP_TILE;
+              shz_seg_blocks(&sp, stile);
+              const uint32_t nsb = sp.bq[nqp];
+              void *cxp, *hist;
+              SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT5, (uint64_t)nsb * (cpb + 1) * 4, &cxp));
+              SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_H, ((uint64_t)nsb << 8) * 4, &hist));   // (the sort asks for the same)
+              hipLaunchKernelGGL(m_chunk_start_kernel, dim3(nblk((uint64_t)nsb * (cpb + 1))), dim3(256), 0, ctx->stream,
+                                 (const uint64_t*)po, (uint32_t)nx, sp, stile, vp.v_lo, vp.v_hi, (uint32_t*)cxp);
+              hipLaunchKernelGGL(m_expand_blocks_kernel, dim3(nsb), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                                 (const uint32_t*)gs, (const uint32_t*)cxp, (const uint64_t*)po, (const uint32_t*)glo,
+                                 (const shz_seg_dev*)d_segs, (uint32_t)nseg, vp.v_lo, sp, stile, mbp, pl.g_lo, fuse_dmask, k32,
+                                 (uint32_t*)hist);
+              SHZ_HIP(ctx, hipGetLastError());
+            }
             int sel = 0;
-            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax4, pp, pl.g_lo, Bt, sp, &sel));
+            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax4, pp, pl.g_lo, Bt, sp, &sel, fuse));
             const uint32_t* ks = sel ? k32 + pmax4 : k32;
             // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
             void *ts, *cp, *cd, *cdd;
