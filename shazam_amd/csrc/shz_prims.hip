@@ -188,6 +188,26 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 #define SORT_ROUNDS 16
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
 
+// Rank of a lane among the valid lanes of its wave row that hold the same digit d (in lane order: stable), and their
+// number.  One ballot per digit bit; the mask of a lane's peers is kept as two 32-bit halves so that every bit costs a
+// compare and two three-input bit operations (peers & (ballot ^ nl), nl = 0 where the lane's bit is set, ~0 where it is
+// clear) -- the 64-bit select the obvious form compiles to cost eleven instructions per bit, and the scatter kernels are
+// bound by instruction issue (110 VALU instructions per row of 64 keys before).
+template <int BITS>
+__device__ __forceinline__ void wave_digit_rank(uint32_t d, bool valid, uint32_t& rk, uint32_t& cnt) {
+  const unsigned long long v = __ballot(valid);
+  uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const uint32_t nl = ((d >> b) & 1u) - 1u;
+    const unsigned long long m = __ballot(nl == 0u);
+    plo &= (uint32_t)m ^ nl;
+    phi &= (uint32_t)(m >> 32) ^ nl;
+  }
+  rk = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+  cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+}
+
 template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
                                                                   uint32_t dmask /*digit mask: the last digit may be narrower*/,
@@ -285,22 +305,16 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   }
   __syncthreads();
   uint32_t rank[ROWS];
-  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
     const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
-    unsigned long long peers = __ballot(valid);   // valid lanes of this row holding the same digit
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    uint32_t rk, same;
+    wave_digit_rank<BITS>(d, valid, rk, same);
     const uint32_t run = wrun[wave][d];
     rank[r] = run + rk;
-    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + same);
   }
   __syncthreads();
 #pragma unroll
@@ -353,7 +367,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_small_kernel(uint64_t* __re
     sk[0][i] = keys[i];
     if (VB != 0) sv[0][i] = vals[i];
   }
-  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int p = 0; p < npass; ++p) {
     const int cur = p & 1, shift = bit_lo + 8 * p;
     const uint32_t dmask = (1u << min(8, bit_hi - shift)) - 1u;   // the last digit may be narrower
@@ -368,16 +381,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_small_kernel(uint64_t* __re
       const bool valid = li < n;
       k[r] = valid ? sk[cur][li] : 0;
       const uint32_t d = (uint32_t)(k[r] >> shift) & dmask;
-      unsigned long long peers = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const unsigned long long m = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? m : ~m;
-      }
-      const uint32_t rk = (uint32_t)__popcll(peers & lt);
+      uint32_t rk, same;
+      wave_digit_rank<8>(d, valid, rk, same);
       const uint32_t run = wrun[wave][d];
       rank[r] = run + rk;
-      if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+      if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + same);
     }
     __syncthreads();
     {
@@ -555,22 +563,16 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter32_kernel(const uint
   }
   __syncthreads();
   uint32_t rank[ROWS];
-  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
     const uint32_t d = (k[r] >> shift) & dmask;
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    uint32_t rk, same;
+    wave_digit_rank<BITS>(d, valid, rk, same);
     const uint32_t run = wrun[wave][d];
     rank[r] = run + rk;
-    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + same);
   }
   __syncthreads();
 #pragma unroll
@@ -777,22 +779,16 @@ __global__ __launch_bounds__(64 * NW) void sort_scatter32_seg_kernel(const uint3
   }
   __syncthreads();
   uint32_t rank[ROWS];
-  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const uint32_t li = (uint32_t)wave * (ROWS * 64) + (uint32_t)r * 64 + lane;
     const bool valid = li < tile_n;
     const uint32_t d = (k[r] >> shift) & dmask;
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const uint32_t rk = (uint32_t)__popcll(peers & lt);
+    uint32_t rk, same;
+    wave_digit_rank<BITS>(d, valid, rk, same);
     const uint32_t run = wrun[wave][d];
     rank[r] = run + rk;
-    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + (uint32_t)__popcll(peers));
+    if (valid && rk == 0) wrun[wave][d] = (uint16_t)(run + same);
   }
   __syncthreads();
   if (owner) {
