@@ -190,19 +190,19 @@ int32_t shz_scan_u64(shz_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64
 
 // Rank of a lane among the valid lanes of its wave row that hold the same digit d (in lane order: stable), and their
 // number.  One ballot per digit bit; the mask of a lane's peers is kept as two 32-bit halves so that every bit costs a
-// compare and two three-input bit operations (peers & (ballot ^ nl), nl = 0 where the lane's bit is set, ~0 where it is
-// clear) -- the 64-bit select the obvious form compiles to cost eleven instructions per bit, and the scatter kernels are
-// bound by instruction issue (110 VALU instructions per row of 64 keys before).
+// sign-extended bit field, a compare and two three-input bit operations (v_bitop3_b32: peers & ~(ballot ^ L), L = ~0 where
+// the lane's bit is set, 0 where it is clear) -- the 64-bit select the obvious form compiles to cost eleven instructions
+// per bit, and the scatter kernels are bound by instruction issue (110 VALU instructions per row of 64 keys before).
 template <int BITS>
 __device__ __forceinline__ void wave_digit_rank(uint32_t d, bool valid, uint32_t& rk, uint32_t& cnt) {
   const unsigned long long v = __ballot(valid);
   uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
 #pragma unroll
   for (int b = 0; b < BITS; ++b) {
-    const uint32_t nl = ((d >> b) & 1u) - 1u;
-    const unsigned long long m = __ballot(nl == 0u);
-    plo &= (uint32_t)m ^ nl;
-    phi &= (uint32_t)(m >> 32) ^ nl;
+    const uint32_t L = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);   // ~0 where the lane's bit is set, 0 where it is clear
+    const unsigned long long m = __ballot(L != 0u);
+    plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, L, 0x90);          // plo & ~(m ^ L)
+    phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), L, 0x90);
   }
   rk = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
   cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(64 * NW) void sort_scatter32_seg_kernel(const uint3
     if (owner) {
 #pragma unroll
       for (int i = 0; i < DPT; ++i) {
-        gbase[threadIdx.x * DPT + i] = g0[i];
+        gbase[threadIdx.x * DPT + i] = g0[i] - ls;   // destination of local position i: gbase[d] + i (mod 2^32)
         lstart[threadIdx.x * DPT + i] = (uint16_t)ls;
         ls += c[i];
       }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64 * NW) void sort_scatter32_seg_kernel(const uint3
   for (uint32_t i = threadIdx.x; i < tile_n; i += THREADS) {
     const uint32_t kk = skey[i];
     const uint32_t d = (kk >> shift) & dmask;
-    okeys[gbase[d] + (i - lstart[d])] = kk;
+    okeys[gbase[d] + i] = kk;
   }
 }
 
