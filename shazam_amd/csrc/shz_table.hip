@@ -564,7 +564,7 @@ __global__ void m_chunk_start_kernel(const uint64_t* __restrict__ po, uint32_t n
   cx[e] = l;
 }
 
-__global__ __launch_bounds__(256) void m_expand_blocks_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
+__global__ __launch_bounds__(256, 8) void m_expand_blocks_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
                                                               const uint32_t* __restrict__ cx, const uint64_t* __restrict__ po,
                                                               const uint32_t* __restrict__ g_lo,
                                                               const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint64_t v_lo,
