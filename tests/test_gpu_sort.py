@@ -90,3 +90,23 @@ def test_segmented_sort32(sizes, bits):
         seg = keys[int(off[i]):int(off[i + 1])]
         order = np.argsort((seg & mask) >> np.uint32(lo), kind="stable")
         assert np.array_equal(got[int(off[i]):int(off[i + 1])], seg[order]), (i, sizes[i])
+
+
+def test_segmented_sort32_large_blocks():
+    """2^24 keys and more: the sort cuts its segments into blocks of 8,192 keys (shz_seg_tile) -- same order."""
+    import shazam_amd as S
+    ctx = S.get_context(0)
+    sizes = [9_000_000, 0, 5, 7_800_001, 8193]
+    rng = np.random.default_rng(2024)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(off[-1])
+    assert n >= 1 << 24
+    keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    keys[1000:3_000_000] &= np.uint32(0x7FFF)                 # three million keys with every sorted bit equal: one long run
+    lo, hi = 15, 31
+    got = ctx.sort_keys32_seg(keys, off, lo, hi)
+    mask = np.uint32((((1 << (hi - lo)) - 1) << lo) & 0xFFFFFFFF)
+    for i in range(len(sizes)):
+        seg = keys[int(off[i]):int(off[i + 1])]
+        order = np.argsort((seg & mask) >> np.uint32(lo), kind="stable")
+        assert np.array_equal(got[int(off[i]):int(off[i + 1])], seg[order]), (i, sizes[i])
