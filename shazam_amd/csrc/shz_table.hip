@@ -1128,12 +1128,7 @@ __device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const u
     p1[r] = p2[r] = valid[r];
     fresh1[r] = fresh2[r] = false;
   }
-  for (uint32_t round = 0;; ++round) {
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < N; ++r) any |= p1[r] | p2[r];
-    if (!any) break;
-    if (round >= probe_limit) { atomicOr(err, 1u); break; }   // (the slots of the lanes that gave up are valid indices of the wrong entries)
+  auto round = [&]() {
     uint32_t o1[N], o2[N];
 #pragma unroll
     for (int r = 0; r < N; ++r) {
@@ -1142,17 +1137,32 @@ __device__ __forceinline__ void vt_slots(uint32_t* key1, uint32_t* key2, const u
     }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
-      if (p1[r]) {
-        if (o1[r] == VT_EMPTY) { fresh1[r] = true; p1[r] = false; }
-        else if (o1[r] == x1[r]) p1[r] = false;
-        else s1[r] = (s1[r] + 1) & ((1u << B1) - 1u);
-      }
-      if (p2[r]) {
-        if (o2[r] == VT_EMPTY) { fresh2[r] = true; p2[r] = false; }
-        else if (o2[r] == x2[r]) p2[r] = false;
-        else s2[r] = (s2[r] + 1) & ((1u << B2) - 1u);
-      }
+      const bool e1 = p1[r] && o1[r] == VT_EMPTY, e2 = p2[r] && o2[r] == VT_EMPTY;
+      fresh1[r] = fresh1[r] || e1;
+      fresh2[r] = fresh2[r] || e2;
+      p1[r] = p1[r] && !e1 && o1[r] != x1[r];
+      p2[r] = p2[r] && !e2 && o2[r] != x2[r];
+      if (p1[r]) s1[r] = (s1[r] + 1) & ((1u << B1) - 1u);
+      if (p2[r]) s2[r] = (s2[r] + 1) & ((1u << B2) - 1u);
     }
+  };
+  auto pending = [&]() {
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < N; ++r) any |= p1[r] | p2[r];
+    return __ballot(any) != 0ull;   // uniform
+  };
+  // The first rounds are straight-line code: at the fill levels the callers keep, two or three rounds settle a row, and
+  // outside a loop the lanes' states (pending, fresh) stay lane masks in scalar registers -- as loop-carried values of a
+  // divergent loop they were re-materialised per round (35 VALU instructions per round; vt_stream_kernel is bound by VALU
+  // issue).  Whatever is still pending goes round a wave-uniform loop.
+  constexpr uint32_t STRAIGHT = 3;
+  round();                                   // (probe_limit >= 1)
+  if (probe_limit > 1) round();
+  if (probe_limit > 2) round();
+  for (uint32_t done = probe_limit < STRAIGHT ? probe_limit : STRAIGHT; pending(); ++done) {
+    if (done >= probe_limit) { atomicOr(err, 1u); break; }   // (the slots of the lanes that gave up are valid indices of the wrong entries)
+    round();
   }
 }
 
