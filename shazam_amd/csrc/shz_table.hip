@@ -1539,8 +1539,8 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
       { const uint32_t i = base + 256 + lane; r3 = i < b ? k[i] : 0u; }
       const bool valid = base + lane < b;
       const uint32_t hi = v >> pl.g_lo;
-      uint32_t hp = (uint32_t)__shfl_up((int)hi, 1, 64);
-      if (lane == 0) hp = last_hi;
+      // the neighbour lane's upper bits (lane 0: the previous row's last) -- a DPP wave shift, not a trip through the LDS crossbar
+      const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)last_hi, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
       const unsigned long long mg = __ballot(valid && hi != hp);     // lanes that open a group
       last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);    // (the last row is the only partial one)
       uint32_t lo = 0;                               // first lane of the row not dealt with yet
