@@ -199,6 +199,15 @@ __device__ __forceinline__ float stage_value<float>(double p) {
 __device__ __forceinline__ int stft_sz(int s) {
   return s ^ (((s >> 4) & 1) << 1) ^ (((s >> 5) & 1) * 9) ^ (((s >> 6) & 1) << 2) ^ (((s >> 8) & 1) << 3);
 }
+// LDS accesses are written on BYTE offsets (slot << 4, the constants of a pass scaled alike): with element indices the
+// compiler shifted every one of the 66 addresses of a frame by four again (and the kernel is bound by VALU issue).
+__device__ __forceinline__ int stft_szb(int s) { return stft_sz(s) << 4; }
+__device__ __forceinline__ cplx& lds_at(cplx* buf, int byte_off) {
+  return *reinterpret_cast<cplx*>(reinterpret_cast<char*>(buf) + byte_off);
+}
+__device__ __forceinline__ const cplx& lds_at(const cplx* buf, int byte_off) {
+  return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(buf) + byte_off);
+}
 // ---- the pieces of a frame (stft_frame = one frame; stft_psd2_kernel interleaves the pieces of two) ----
 struct stft_tabs { const cplx *tw, *tw2, *tw3; };
 __device__ __forceinline__ stft_tabs stft_tabs_at(const cplx* tw) { return stft_tabs{tw, tw + TW_MAIN, tw + TW_MAIN + TW_P2}; }
@@ -206,48 +215,48 @@ __device__ __forceinline__ stft_tabs stft_tabs_at(const cplx* tw) { return stft_
 // pass 1: Ns = 1 (no twiddles); A1[8j + r] at slot 8j + r
 __device__ __forceinline__ void stft_p1(cplx (&v)[8], cplx* buf, int j) {
   dft8f(v);
-  const int a = stft_sz(8 * j);   // the low three bits hold swizzle terms only
+  const int a = stft_szb(8 * j);   // the low three slot bits hold swizzle terms only
 #pragma unroll
-  for (int r = 0; r < 8; ++r) buf[a ^ r] = v[r];
+  for (int r = 0; r < 8; ++r) lds_at(buf, a ^ (r << 4)) = v[r];
 }
 // pass 2: Ns = 8, twiddles W_64^(k t) from the table.  Butterfly j2 = L[2:0] | W << 3 | L[5:3] << 5 (a wave takes the
 // butterflies whose bits 3,4 spell its number): inputs A1[j2 + 256 t] at slots j2 + 256 t, results written back there.
 __device__ __forceinline__ void stft_p2_load(cplx (&v)[8], const cplx* buf, int j) {
   const int W = j >> 6, L = j & 63;
   const int j2 = (L & 7) | (W << 3) | ((L >> 3) << 5);
-  const int a0 = stft_sz(j2), a1 = stft_sz(j2 | 256);   // t even / odd (slot bit 8 enters the swizzle)
+  const int a0 = stft_szb(j2), a1 = stft_szb(j2 | 256);   // t even / odd (slot bit 8 enters the swizzle)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) v[t] = buf[((t & 1) ? a1 : a0) + (t >> 1) * 512];
+  for (int t = 0; t < 8; ++t) v[t] = lds_at(buf, ((t & 1) ? a1 : a0) + (t >> 1) * (512 << 4));
 }
 __device__ __forceinline__ void stft_p2_rest(cplx (&v)[8], cplx* buf, const stft_tabs& T, int j) {
   const int W = j >> 6, L = j & 63;
   const int j2 = (L & 7) | (W << 3) | ((L >> 3) << 5);
-  const int a0 = stft_sz(j2), a1 = stft_sz(j2 | 256);
+  const int a0 = stft_szb(j2), a1 = stft_szb(j2 | 256);
   const int k = L & 7;
 #pragma unroll
   for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw2[(t - 1) * 8 + k]);
   dft8f(v);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) buf[((r & 1) ? a1 : a0) + (r >> 1) * 512] = v[r];
+  for (int r = 0; r < 8; ++r) lds_at(buf, ((r & 1) ? a1 : a0) + (r >> 1) * (512 << 4)) = v[r];
 }
 // pass 3: Ns = 64, twiddles W_512^(k t).  Butterfly j: inputs A2[j + 256 t] at slots j[2:0] | W << 3 | t << 5 | j[5:3] << 8
 // -- all written by this wave in pass 2: no barrier in front.  Slot bits 5 and 6 (t & 1, t & 2) enter the swizzle, bit 7
 // (t & 4) is a plain offset of 128 elements.
 __device__ __forceinline__ void stft_p3_load(cplx (&v)[8], const cplx* buf, int j) {
-  const int b3 = stft_sz((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
-  const int q0 = b3, q1 = (b3 ^ 9) + 32, q2 = (b3 ^ 4) + 64, q3 = (b3 ^ 13) + 96;
+  const int b3 = stft_szb((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
+  const int q0 = b3, q1 = (b3 ^ (9 << 4)) + (32 << 4), q2 = (b3 ^ (4 << 4)) + (64 << 4), q3 = (b3 ^ (13 << 4)) + (96 << 4);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) v[t] = buf[((t & 3) == 0 ? q0 : (t & 3) == 1 ? q1 : (t & 3) == 2 ? q2 : q3) + (t >> 2) * 128];
+  for (int t = 0; t < 8; ++t) v[t] = lds_at(buf, ((t & 3) == 0 ? q0 : (t & 3) == 1 ? q1 : (t & 3) == 2 ? q2 : q3) + (t >> 2) * (128 << 4));
 }
 __device__ __forceinline__ void stft_p3_rest(cplx (&v)[8], cplx* buf, const stft_tabs& T, int j) {
-  const int b3 = stft_sz((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
-  const int q0 = b3, q1 = (b3 ^ 9) + 32, q2 = (b3 ^ 4) + 64, q3 = (b3 ^ 13) + 96;
+  const int b3 = stft_szb((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
+  const int q0 = b3, q1 = (b3 ^ (9 << 4)) + (32 << 4), q2 = (b3 ^ (4 << 4)) + (64 << 4), q3 = (b3 ^ (13 << 4)) + (96 << 4);
   const int k = j & 63;
 #pragma unroll
   for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw3[(t - 1) * 64 + k]);
   dft8f(v);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) buf[((r & 3) == 0 ? q0 : (r & 3) == 1 ? q1 : (r & 3) == 2 ? q2 : q3) + (r >> 2) * 128] = v[r];
+  for (int r = 0; r < 8; ++r) lds_at(buf, ((r & 3) == 0 ? q0 : (r & 3) == 1 ? q1 : (r & 3) == 2 ? q2 : q3) + (r >> 2) * (128 << 4)) = v[r];
 }
 // pass 4 + split post-pass, no trip through LDS between them.  Pass 4: Ns = 512, radix 4, twiddles
 // W_2048^(b t) = W4096^(2 b t); butterfly b yields Z[b + 512 c], c = 0..3.  The post-pass pairs Z[k] with
@@ -258,10 +267,10 @@ __device__ __forceinline__ void stft_p3_rest(cplx (&v)[8], cplx* buf, const stft
 // flips swizzle bit 1); v[0..3] = butterfly j, v[4..7] = butterfly 512 - j (thread 0: 256).
 __device__ __forceinline__ void stft_p4_load(cplx (&v)[8], const cplx* buf, int j) {
   const int bb = j == 0 ? 256 : 512 - j;
-  auto slot4 = [](int b) { return stft_sz((b & 7) | (((b >> 6) & 7) << 5) | (((b >> 3) & 7) << 8)); };
+  auto slot4 = [](int b) { return stft_szb((b & 7) | (((b >> 6) & 7) << 5) | (((b >> 3) & 7) << 8)); };
   const int sa = slot4(j), sb = slot4(bb);
-  v[0] = buf[sa]; v[1] = buf[sa ^ 8]; v[2] = buf[sa ^ 18]; v[3] = buf[sa ^ 26];
-  v[4] = buf[sb]; v[5] = buf[sb ^ 8]; v[6] = buf[sb ^ 18]; v[7] = buf[sb ^ 26];
+  v[0] = lds_at(buf, sa); v[1] = lds_at(buf, sa ^ (8 << 4)); v[2] = lds_at(buf, sa ^ (18 << 4)); v[3] = lds_at(buf, sa ^ (26 << 4));
+  v[4] = lds_at(buf, sb); v[5] = lds_at(buf, sb ^ (8 << 4)); v[6] = lds_at(buf, sb ^ (18 << 4)); v[7] = lds_at(buf, sb ^ (26 << 4));
 }
 // Twiddles: butterfly 512 - j uses W^(1024 - 2j) and its powers, mirrors of butterfly j's (tw_mirror): W1' = -i conj(W1),
 // W2' = -conj(W2), W3' = i conj(W3); the post-pass needs W^j, W^(512-j) and their mirrors W^(1024-j), W^(512+j).
