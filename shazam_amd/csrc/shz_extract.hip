@@ -11,6 +11,7 @@
 //   mask     u64 [frame][n_slabs][4]  one bit per (frame, bin): peak          (stage buffer)
 //   peak_f/t u16/u32 in (clip, t asc, f asc) order                             (stage buffer)
 //   key32/t1 u32 in the reference's generation order                           (output)
+#include <type_traits>
 #include <algorithm>
 
 #include "shz_internal.h"
@@ -79,6 +80,7 @@ struct stft_args {
   const double* window;        // [4096]
   const cplx* tw;              // [1025] W4096^k
   double scale;                // 0.25 / (Fs * sum(w^2))
+  uint32_t opt;                // experiment switches (SHZ_STFT_OPT): 1 = no rotation of the special wave, 2 = one frame loop for all waves
 };
 
 // The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
@@ -322,7 +324,8 @@ __device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, i
   if (t0) pair_out(1024, make_double2(0.0, -1.0), A2, A2);
 }
 
-template <class PRE, class OUT>
+// SPECIAL = false: the caller knows that its wave does not hold thread 0 (see stft_psd_kernel)
+template <bool SPECIAL = true, class PRE, class OUT>
 __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, double scale, PRE&& before_out, OUT&& out) {
   cplx* buf = lds;
   const stft_tabs T = stft_tabs_at(lds + 2048);
@@ -337,9 +340,9 @@ __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, doubl
   stft_p4_load(v, buf, j);
   __syncthreads();  // everybody holds its inputs: buf may be rewritten by the next frame's pass 1
   // thread 0's butterflies pair differently: the selects that say so cost 36 instructions per frame
-  // (running the select-free variant in waves 1-3 behind a wave-uniform branch was tried: the split basic blocks cost
-  // 76 spilled registers against 16)
-  stft_p4_rest<true>(v, T, j, scale, before_out, out);
+  // (a wave-uniform branch around this call alone was tried: everything live in the frame crosses the split, 76 spilled
+  // registers against 16 -- the kernel branches once, outside the frame loop, instead)
+  stft_p4_rest<SPECIAL>(v, T, j, scale, before_out, out);
 }
 
 #define P32_STRIDE 2064  // floats per fp32 row: 2049 bins padded so every row starts 64-byte aligned
@@ -350,7 +353,9 @@ __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, doubl
 template <typename T>
 __global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   __shared__ cplx lds[LDS_CPLX];
-  const int j = threadIdx.x;
+  // logical thread number: the wave that plays "wave 0" (thread 0's extra selects, see the end of this kernel) differs from
+  // workgroup to workgroup, so that the three workgroups of a CU do not put their heavier wave on the same SIMD
+  const int j = (int)threadIdx.x ^ (int)((a.opt & 1u) ? 0u : (blockIdx.x & 3u) << 6);
   stft_tables(lds, a.tw, j, 256);
   __syncthreads();
   constexpr uint32_t STRIDE = sizeof(T) == 8 ? DB_STRIDE : P32_STRIDE;
@@ -396,16 +401,24 @@ __global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   }
   if (g0 < gend) issue_loads(g0);
 
-  for (uint32_t g = g0; g < gend; g += gstep) {
-    cplx v[8];
+  // Two copies of the frame loop: wave 0 (it holds thread 0, whose last butterflies pair differently) runs the one with the
+  // selects, waves 1-3 the one without (36 of ~490 vector instructions per frame).  The branch is taken ONCE, on a scalar
+  // condition, so nothing of a frame's state is live across it; both copies meet at the same three barriers per frame.
+  auto frames = [&](auto special_c) {
+    constexpr bool SPECIAL = decltype(special_c)::value;
+    for (uint32_t g = g0; g < gend; g += gstep) {
+      cplx v[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      v[t] = make_double2((double)(short)(pw[t] & 0xFFFF) * ww[t].x, (double)(pw[t] >> 16) * ww[t].y);
-    T* orow = reinterpret_cast<T*>(a.out) + (uint64_t)g * STRIDE;
-    stft_frame(
-        v, lds, j, a.scale, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
-        [&](int k, double p) { orow[k] = stage_value<T>(p); });
-  }
+      for (int t = 0; t < 8; ++t)
+        v[t] = make_double2((double)(short)(pw[t] & 0xFFFF) * ww[t].x, (double)(pw[t] >> 16) * ww[t].y);
+      T* orow = reinterpret_cast<T*>(a.out) + (uint64_t)g * STRIDE;
+      stft_frame<SPECIAL>(
+          v, lds, j, a.scale, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
+          [&](int k, double p) { orow[k] = stage_value<T>(p); });
+    }
+  };
+  if (__builtin_amdgcn_readfirstlane(j) < 64 || (a.opt & 2u)) frames(std::true_type{});
+  else frames(std::false_type{});
 }
 
 // ======================================================================================
@@ -1199,6 +1212,8 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
   a.frames_per_wg = 0;
+  static const uint32_t opt_env = [] { const char* e = getenv("SHZ_STFT_OPT"); return e ? (uint32_t)atoi(e) : 0u; }();
+  a.opt = opt_env;
   return a;
 }
 
