@@ -6,6 +6,8 @@ tables that exercise each of its cases:
   wide    70,000 songs: 5 song-id bits stay unordered inside a tile group, passes of up to 16 queries
   tonal   64 copies of a stationary eight-tone song under consecutive ids far up the id range: one tile group carries
           thousands of distinct (song, delta) pairs, so the tile must be swept in several parts
+  gaps    one pass of 24 queries of which every fourth has no hashes, every fourth only hashes the table does not hold and
+          every fourth seven hashes: empty segments and blocks of a few votes between ordinary ones
   topn20  top-20 (beyond the tile path's limit) over several vote passes with two-level top-n: regression test for the
           fold's candidate buffers, which used to live in the workspace slots of the probe's group tables
 
@@ -96,6 +98,38 @@ elif case == "tonal":
     k2 = np.concatenate([qk, sq[0]]); t2 = np.concatenate([qt, sq[1]])
     o2 = np.concatenate([qo, qo[-1] + sq[2][1:]])
     run(k2, t2, o2, 4)
+elif case == "gaps":
+    # a pass whose segments include empty ones: queries without hashes, queries whose hashes the table does not hold,
+    # queries of a handful of hashes -- between ordinary ones (the expand runs by the sort's blocks: blocks of a few votes,
+    # segments without blocks)
+    n, nc = 8 * 44100, 3000
+    add_synth(55, nc, n, 1)
+    tbl.finalize()
+    tids = rng.integers(0, nc, 24)
+    qk, qt, qo = synth_queries(55, tids, n, 5 * 44100)
+    ks, ts, offs, expect = [], [], [0], []
+    for i in range(24):
+        a, b = int(qo[i]), int(qo[i + 1])
+        kind = i %% 4
+        if kind == 1:      # no hashes at all
+            kq, tq = qk[:0], qt[:0]
+        elif kind == 2:    # hashes of keys no track has (f1 = f2 = 2047 never occurs: dt > 0 there is no such pair)
+            kq = np.full(40, (2047 << 20) | (2047 << 8) | 3, np.uint32) + np.arange(40, dtype=np.uint32) %% 5
+            tq = np.arange(40, dtype=np.uint32)
+        elif kind == 3:    # a handful of the query's hashes
+            kq, tq = qk[a:a + 7], qt[a:a + 7]
+        else:
+            kq, tq = qk[a:b], qt[a:b]
+            expect.append((len(offs) - 1, 1 + int(tids[i])))
+        ks.append(kq); ts.append(tq); offs.append(offs[-1] + len(kq))
+    k2, t2, o2 = np.concatenate(ks), np.concatenate(ts), np.array(offs, np.uint64)
+    for topn in (1, 3):
+        res = tbl.match(k2, t2, o2, topn)
+        for q, sid in expect:
+            assert int(res["sid"][q, 0]) == sid, (q, sid)
+        assert int(res["nres"][1]) == 0 and int(res["npairs"][2]) == 0
+        for name in sorted(res):
+            h.update(np.ascontiguousarray(res[name]).tobytes())
 elif case == "topn20":
     n, nc = 30 * 44100, 12000
     add_synth(5, nc, n, 1)
@@ -117,7 +151,7 @@ def _run(case, vote32, tiles):
     return out.stdout.strip().split()
 
 
-@pytest.mark.parametrize("case", ["small", "wide", "tonal"])
+@pytest.mark.parametrize("case", ["small", "wide", "tonal", "gaps"])
 def test_vote_tiles_equal_full_sort(case):
     base = _run(case, 0, 0)                      # 8-byte votes, one pass, full sort
     assert int(base[1]) > 8192
