@@ -70,6 +70,9 @@ struct mctl {
   unsigned long long pad[3];
   unsigned int err[4];        // [0] offset too wide, [1] largest query offset, [2] hashes this shard owns
 };
+// rows under the probed keys: striped over the 8-byte words [16, 16 + M_ROW_STRIPES) of the 256-byte control block
+#define M_ROW_STRIPES 16
+static_assert(sizeof(mctl) <= 128 && 128 + M_ROW_STRIPES * 8 <= 256, "the stripes sit in the second half of the control block");
 // the filler element that stands for the hashes other shards own sorts last: it is not an element
 __global__ void m_fix_mu_kernel(mctl* c, unsigned long long m) {
   if (c->err[2] < m && c->mu) --c->mu;
@@ -355,7 +358,9 @@ __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* _
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor((long long)s, d, 64);
-  if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total, s);
+  // (statistics only.  One word for all waves cost more than the searches: 31,000 atomics on one address per call; the
+  // count is kept in M_ROW_STRIPES words of the control block instead and summed on the host)
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(rows_total + (blockIdx.x & (M_ROW_STRIPES - 1)), s);
 }
 
 __global__ void m_query_stats_kernel(const uint64_t* __restrict__ E, const mctl* __restrict__ ctl,
@@ -1916,7 +1921,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     }
     hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx_bound)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
                        (const uint32_t*)gs, &d_ctl->ng, nx_bound, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
-                       (uint64_t*)gpairs, &d_ctl->rows);
+                       (uint64_t*)gpairs, (unsigned long long*)ctl_p + 16);
     SHZ_HIP(ctx, hipGetLastError());
     SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx_bound, tot + 3));
     // results and per-query counters in ONE device block: one fill before, one copy after.
@@ -1997,7 +2002,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     // plans the vote passes (behind a queued small query: its results come along)
     void* mailp;
     SHZ_TRY(shz_mailbox(ctx, 256 + (uint64_t)nq * 8 + (spec ? rb_bytes : 0), &mailp));
-    SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, sizeof(mctl), hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipMemcpyAsync(mailp, d_ctl, 256, hipMemcpyDeviceToHost, ctx->stream));
     if (nq > 1) SHZ_HIP(ctx, hipMemcpyAsync((char*)mailp + 256, d_np, (uint64_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (spec) SHZ_HIP(ctx, hipMemcpyAsync((char*)mailp + 256 + 8, rb, rb_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (trace) tr1 = now_s();
@@ -2026,7 +2031,9 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     }
     const uint32_t ng = (uint32_t)h.ng;
     const uint64_t nx = (uint64_t)ng * nseg;   // sub-groups: (query, key) group x segment
-    const uint64_t P = h.P, rows_total = h.rows;
+    const uint64_t P = h.P;
+    uint64_t rows_total = 0;
+    for (int i = 0; i < M_ROW_STRIPES; ++i) rows_total += ((const uint64_t*)mailp)[16 + i];
     if (mu) ctx->m_votes_per_hash = t->votes_per_hash = (double)P / (double)mu;
     if (P > SUB_BUDGET && nq > 1) {  // too many pairs for one sub-batch: retry with fewer queries
       step = std::max<uint32_t>(1, nq / 2);
