@@ -113,6 +113,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_loop_kernel(In in, T* __res
   if (total && threadIdx.x == 0) *total = (uint64_t)carry;
 }
 
+// Two launches instead of three for up to SCAN_FLAT_TILES tiles: every workgroup adds up the sums of the tiles in front of
+// it itself (at most a few thousand values from L2) instead of waiting for a launch that scans them.
+#define SCAN_FLAT_TILES 2048
+template <typename T, typename In>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_flat_kernel(In in, T* __restrict__ out, const T* __restrict__ sums,
+                                                                        uint64_t n, uint64_t* __restrict__ total) {
+  __shared__ T lds[8];
+  T pre = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += SCAN_THREADS) pre += sums[i];
+  T before;
+  block_excl_scan(pre, &before, lds);   // before = sum of the tiles in front of this one
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  T v[SCAN_ITEMS];
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? (T)in(base + i) : (T)0;
+    s += v[i];
+  }
+  T tot;
+  T off = block_excl_scan(s, &tot, lds) + before;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = off;
+    off += v[i];
+  }
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = (uint64_t)off;
+}
+
 __global__ void set_u64_kernel(uint64_t* p, uint64_t v) { *p = v; }
 
 template <typename T, typename In>
@@ -136,6 +165,12 @@ static int32_t scan_impl(shz_ctx* ctx, In in, T* d_out, uint64_t n, uint64_t* d_
   if (nb > tmp_elems) SHZ_FAIL(ctx, SHZ_E_INVALID, "scan: temp too small");
   hipLaunchKernelGGL((scan_sums_kernel<T, In>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, tmp, n);
   SHZ_HIP(ctx, hipGetLastError());
+  if (nb <= SCAN_FLAT_TILES) {
+    hipLaunchKernelGGL((scan_apply_flat_kernel<T, In>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, d_out,
+                       (const T*)tmp, n, d_total);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
+  }
   // scan the block sums in place (recursive), using the tail of tmp as the next level's scratch
   if (sizeof(T) == 4) {
     in_u32 nin{(const uint32_t*)tmp};
