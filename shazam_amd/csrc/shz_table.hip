@@ -1929,7 +1929,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
     const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8 + 8;   // + the vote tiles' flag word (and a pad)
     void* rb;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes, &rb));
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes + 64, &rb));
     uint64_t* d_np = (uint64_t*)rb;
     uint32_t* r_sid = (uint32_t*)(d_np + nq);
     uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
@@ -1992,7 +1992,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         SHZ_HIP(ctx, hipGetLastError());
       }
     }
-    if (!spec) SHZ_HIP(ctx, hipMemsetAsync(rb, 0, rb_bytes, ctx->stream));   // (a queued query's first kernel did that)
+    // (a queued query's first kernel did that; whole 64-byte lines: the runtime fills a ragged size in two launches)
+    if (!spec) SHZ_HIP(ctx, hipMemsetAsync(rb, 0, (rb_bytes + 63) & ~63ull, ctx->stream));
     if (nq > 1) {   // one query: its counts are the totals
       hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
                          (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
