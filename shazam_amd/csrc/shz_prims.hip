@@ -235,7 +235,7 @@ __device__ __forceinline__ void wave_digit_rank(uint32_t d, bool valid, uint32_t
 #pragma unroll
   for (int b = 0; b < BITS; ++b) {
     const uint32_t L = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);   // ~0 where the lane's bit is set, 0 where it is clear
-    const unsigned long long m = __ballot(L != 0u);
+    const unsigned long long m = __builtin_amdgcn_uicmp(L, 0u, 33 /* ICMP_NE */);   // the ballot, as ONE compare on L
     plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, L, 0x90);          // plo & ~(m ^ L)
     phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), L, 0x90);
   }
