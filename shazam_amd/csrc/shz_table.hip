@@ -13,15 +13,14 @@ __global__ void m_compose_kernel(const uint32_t* __restrict__ key32, const uint3
                                  uint32_t nshards, uint32_t shard, uint64_t* __restrict__ c, uint32_t* __restrict__ err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // a shard only looks at the hashes it owns; the others collapse into ONE filler element behind the last query
-  // (index nq), which the host drops after the sort.  err[2] counts the owned elements.
+  // (index nq), which the host drops after the sort.  err[2] != 0: some element is not owned (the filler exists).
   const bool own = i < m && (nshards <= 1 || shard_of(key32[query_off[0] + i], nshards) == shard);
-  // (one shard: every element is owned, the count is m -- no atomics.  41,000 waves adding to ONE word, and as many
-  // atomicMax on the next, were what this kernel cost: 0.7 ms per 2.6 M elements)
-  const unsigned long long ob = __ballot(own);
+  // (a flag, set by the first wave that sees a foreign element.  A COUNT of the owned elements kept with one atomicAdd per
+  // wave -- 41,000 waves on ONE word, and as many atomicMax on the next -- was what this kernel cost: 0.7 ms per 2.6 M
+  // elements)
   if (nshards > 1) {
-    if ((threadIdx.x & 63) == 0 && ob) atomicAdd(err + 2, (uint32_t)__popcll(ob));
-  } else if (i == 0) {
-    err[2] = (uint32_t)m;
+    const bool foreign = i < m && !own;
+    if (__ballot(foreign) && (threadIdx.x & 63) == 0 && *(volatile uint32_t*)(err + 2) == 0u) atomicOr(err + 2, 1u);
   }
   // largest query offset (the vote key biases deltas by it) and the "offset too wide" flag: one atomic per wave
   uint32_t o = 0;
@@ -68,14 +67,14 @@ struct mctl {
   unsigned long long P;       // votes
   unsigned long long G;       // (query, song) groups of the votes
   unsigned long long pad[3];
-  unsigned int err[4];        // [0] offset too wide, [1] largest query offset, [2] hashes this shard owns
+  unsigned int err[4];        // [0] offset too wide, [1] largest query offset, [2] some hash belongs to another shard
 };
 // rows under the probed keys: striped over the 8-byte words [16, 16 + M_ROW_STRIPES) of the 256-byte control block
 #define M_ROW_STRIPES 16
 static_assert(sizeof(mctl) <= 128 && 128 + M_ROW_STRIPES * 8 <= 256, "the stripes sit in the second half of the control block");
 // the filler element that stands for the hashes other shards own sorts last: it is not an element
 __global__ void m_fix_mu_kernel(mctl* c, unsigned long long m) {
-  if (c->err[2] < m && c->mu) --c->mu;
+  if (c->err[2] && c->mu) --c->mu;
 }
 // flag[i] = 1 where (c[i] >> shift) differs from its predecessor, for i < *n (0 beyond, up to the launch bound)
 __global__ void m_head_flag_dn_kernel(const uint64_t* __restrict__ c, const unsigned long long* __restrict__ n,
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(MH_THREADS) void m_head_small_kernel(const uint32_t
     ctl->ng = ng;
     ctl->err[0] = (s_omax >> QOFF_BITS) ? 1u : 0u;
     ctl->err[1] = s_omax;
-    ctl->err[2] = m;
+    ctl->err[2] = 0;   // (one shard: nothing is foreign)
   }
 }
 
