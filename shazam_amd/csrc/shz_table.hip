@@ -1747,6 +1747,85 @@ static int32_t vote_fold(shz_ctx* ctx, const uint64_t* vs, uint64_t P, uint32_t 
   return SHZ_OK;
 }
 
+// ---- one vote-tile pass, in two steps so that the producer of the votes may use the plan (m_expand_blocks_kernel counts the
+// first radix pass by the sort's blocks)
+// plan from the votes per query of the pass: vote and tile offsets per query, the bits the radix passes order
+static void vt_make_plan(const uint64_t* counts, uint32_t nqp, const m_bits& mbp, vt_plan& pl, shz_seg_plan& sp) {
+  const int Bt = mbp.sb + mbp.dbits + 1;   // the votes of a tile pass carry no query bits
+  pl.nq = sp.nq = nqp;
+  pl.dbits = mbp.dbits;
+  pl.sb = mbp.sb;
+  pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
+  pl.tile = VW_CHUNK;
+  static const uint32_t flush_env = [] { const char* e = getenv("SHZ_VW_FLUSH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : 0u; }();
+  pl.flush = flush_env ? flush_env : VW_FLUSH;
+  pl.qv[0] = pl.tb[0] = sp.qv[0] = sp.bq[0] = 0;
+  for (uint32_t i = 0; i < nqp; ++i) {
+    const uint64_t c = counts[i];
+    pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[i] + (uint32_t)c;
+    pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + VW_CHUNK - 1) / VW_CHUNK);
+    sp.bq[i + 1] = sp.bq[i] + (uint32_t)((c + 4095) / 4096);   // (the sort fills in its own block size)
+  }
+  for (uint32_t i = nqp; i < VT_MAXQ; ++i) {
+    pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[nqp];
+    pl.tb[i + 1] = pl.tb[nqp];
+    sp.bq[i + 1] = sp.bq[nqp];
+  }
+}
+
+// the pass itself: the pp votes in k32 (4 bytes each, no query bits, query by query as the plan says; k32_alt = the second
+// buffer of the sort) -> two radix passes (the first one already counted: hist0) -> tiles -> per-query top-n in
+// rs / rdl / ra / rd / rn (rows of the pass's first query).  *d_vt_err is set when a tile gave up (the caller repeats the
+// votes through the full sort).
+static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint64_t pp, const vt_plan& pl, const shz_seg_plan& sp,
+                           const m_bits& mbp, uint32_t topn, bool hist0, uint32_t max_sid, uint32_t* d_vt_err, uint32_t* rs,
+                           int32_t* rdl, uint32_t* ra, uint32_t* rd, uint32_t* rn) {
+  const uint32_t nqp = pl.nq;
+  const int Bt = mbp.sb + mbp.dbits + 1;
+  const uint32_t vt_probe_limit_1 = (ctx->debug & SHZ_DEBUG_VT_PROBE1) ? 1u : 0u;   // debug: a probe gives up after one round
+  const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
+  int sel = 0;
+  SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32_alt, pp, pl.g_lo, Bt, sp, &sel, hist0));
+  const uint32_t* ks = sel ? k32_alt : k32;
+  // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
+  void *ts, *cp, *cd, *cdd;
+  const uint64_t ncand = ((uint64_t)nt + hcap) * topn;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, ((uint64_t)nt + 4 + (uint64_t)hcap * 3) * 4, &ts));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT1, ncand * 8, &cp));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT2, ncand * 4, &cd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT3, ncand * 4, &cdd));
+  uint32_t* tile_start = (uint32_t*)ts;
+  uint32_t* n_heavy = tile_start + nt + 1;
+  uint2* heavy = (uint2*)(tile_start + ((nt + 2 + 1) & ~1u));   // 8-byte aligned
+  uint32_t* heavy_q = (uint32_t*)(heavy + hcap);
+  hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)nt + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start, n_heavy);
+  // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
+  const int slb_ = pl.g_lo - 1 - mbp.dbits;
+  const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(max_sid, 1u));
+  static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
+  if (no_qr)
+    hipLaunchKernelGGL((vt_stream_kernel<7, false>), dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+  else if ((double)(1u << slb_) + (double)pl.flush / per_song <= 40.0)
+    hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+  else
+    hipLaunchKernelGGL(vt_stream_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
+                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+  hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
+                     dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
+                     (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
+                     (uint32_t*)cdd + (uint64_t)nt * topn, vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VT_SLOTS, d_vt_err);
+  hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
+                     (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, hcap,
+                     rs, rdl, ra, rd, rn);
+  SHZ_HIP(ctx, hipGetLastError());
+  return SHZ_OK;
+}
+
 static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, const uint32_t* q_off,
                           const uint64_t* query_off, uint32_t n_queries, uint32_t topn, uint32_t flags,
                           uint32_t* out_sid, int32_t* out_delta, uint32_t* out_aligned, uint32_t* out_dedup,
@@ -2179,27 +2258,11 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
           if (tiles) {
             vt_plan pl;
             shz_seg_plan sp;
+            std::vector<uint64_t> counts(nqp);
+            for (uint32_t i = 0; i < nqp; ++i) counts[i] = nq > 1 ? h_votes[vp.qa + i] : pp;
+            vt_make_plan(counts.data(), nqp, mbp, pl, sp);
             const int Bt = mbp.sb + mbp.dbits + 1;   // the votes of a tile pass carry no query bits
-            pl.nq = sp.nq = nqp;
-            pl.dbits = mbp.dbits;
-            pl.sb = mbp.sb;
-            pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
-            pl.tile = VW_CHUNK;
-            static const uint32_t flush_env = [] { const char* e = getenv("SHZ_VW_FLUSH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : 0u; }();
-            pl.flush = flush_env ? flush_env : VW_FLUSH;
-            pl.qv[0] = pl.tb[0] = sp.qv[0] = sp.bq[0] = 0;
-            for (uint32_t i = 0; i < nqp; ++i) {
-              const uint64_t c = nq > 1 ? h_votes[vp.qa + i] : pp;
-              pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[i] + (uint32_t)c;
-              pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + VW_CHUNK - 1) / VW_CHUNK);
-              sp.bq[i + 1] = sp.bq[i] + (uint32_t)((c + 4095) / 4096);
-            }
-            for (uint32_t i = nqp; i < VT_MAXQ; ++i) {
-              pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[nqp];
-              pl.tb[i + 1] = pl.tb[nqp];
-              sp.bq[i + 1] = sp.bq[nqp];
-            }
-            const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
+            (void)Bt;
             if (fuse) {
               const uint32_t stile = shz_seg_tile(pp), cpb = stile / M_EXP_TILE;
               shz_seg_blocks(&sp, stile);
@@ -2215,45 +2278,7 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
                                  (uint32_t*)hist);
               SHZ_HIP(ctx, hipGetLastError());
             }
-            int sel = 0;
-            SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32 + pmax4, pp, pl.g_lo, Bt, sp, &sel, fuse));
-            const uint32_t* ks = sel ? k32 + pmax4 : k32;
-            // tile starts | counter of handed-over ranges | the ranges | their queries; candidates of tiles, then of ranges
-            void *ts, *cp, *cd, *cdd;
-            const uint64_t ncand = ((uint64_t)nt + hcap) * topn;
-            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT0, ((uint64_t)nt + 4 + (uint64_t)hcap * 3) * 4, &ts));
-            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT1, ncand * 8, &cp));
-            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT2, ncand * 4, &cd));
-            SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT3, ncand * 4, &cdd));
-            uint32_t* tile_start = (uint32_t*)ts;
-            uint32_t* n_heavy = tile_start + nt + 1;
-            uint2* heavy = (uint2*)(tile_start + ((nt + 2 + 1) & ~1u));   // 8-byte aligned
-            uint32_t* heavy_q = (uint32_t*)(heavy + hcap);
-            hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)nt + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start, n_heavy);
-            // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
-            const int slb_ = pl.g_lo - 1 - mbp.dbits;
-            const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(t->max_sid, 1u));
-            static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
-            if (no_qr)
-              hipLaunchKernelGGL((vt_stream_kernel<7, false>), dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
-            else if ((double)(1u << slb_) + (double)pl.flush / per_song <= 40.0)
-              hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
-            else
-              hipLaunchKernelGGL(vt_stream_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                                 (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                                 vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
-            hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
-                               dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
-                               (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
-                               (uint32_t*)cdd + (uint64_t)nt * topn, vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VT_SLOTS, d_vt_err);
-            hipLaunchKernelGGL(vt_rank_kernel, dim3(nqp), dim3(VR_THREADS), 0, ctx->stream, pl, topn, mbp, (const uint64_t*)cp,
-                               (const uint32_t*)cd, (const uint32_t*)cdd, (const uint32_t*)n_heavy, (const uint32_t*)heavy_q, hcap,
-                               rs, rdl, ra, rd, r_n + vp.qa);
-            SHZ_HIP(ctx, hipGetLastError());
+            SHZ_TRY(vt_run_pass(ctx, k32, k32 + pmax4, pp, pl, sp, mbp, topn, fuse, t->max_sid, d_vt_err, rs, rdl, ra, rd, r_n + vp.qa));
           } else {
             SHZ_TRY(shz_sort_u32_widen(ctx, k32, k32 + pmax4, (uint64_t*)v1, pp, 1, B, 0, nullptr));
             SHZ_TRY(vote_fold(ctx, (const uint64_t*)v1, pp, nqp, mbp, topn, tot + 4, rs, rdl, ra, rd, r_n + vp.qa));
