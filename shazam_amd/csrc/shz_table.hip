@@ -2425,6 +2425,93 @@ extern "C" int32_t shz_pairs_allgather(shz_comm* c, uint64_t n_local, const uint
   return SHZ_OK;
 }
 
+// ---- the gathered votes of a sharded match through the vote tiles
+// first vote of every query in the pairs ordered by query: qstart[q] = first i with (pairs[i] >> shift) >= q, q = 0 .. nq
+__global__ void pv_qstart_kernel(const uint64_t* __restrict__ pairs, uint64_t n, int shift, uint32_t nq,
+                                 unsigned long long* __restrict__ qstart) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > nq) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if ((pairs[mid] >> shift) < q) lo = mid + 1; else hi = mid;
+  }
+  qstart[q] = lo;
+}
+// the 4-byte vote of the tiles: a pair without its query bits
+__global__ void pv_narrow_kernel(const uint64_t* __restrict__ pairs, uint64_t n, uint32_t mask, uint32_t* __restrict__ k32) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    k32[i] = (uint32_t)pairs[i] & mask;
+}
+
+// Votes of shz_match_pairs (8 bytes, query index on top) -> results, by the path of the unsharded match: ONE stable sort
+// by the query bits (one or two passes over 8 bytes instead of the five of the full key), the query bits dropped, then
+// the vote-tile passes over 4-byte votes.  Returns false (nothing written) when the layout does not fit the tiles; *redo is
+// set when a tile gave up and the votes have to go through the full sort after all.
+static int32_t pairs_vote_tiles(shz_ctx* ctx, uint64_t* d_pairs, uint64_t* d_alt, uint64_t n, uint32_t nq, const m_bits& mb,
+                                uint32_t topn, uint32_t* r_sid, int32_t* r_delta, uint32_t* r_al, uint32_t* r_dd, uint32_t* r_n,
+                                bool* done, bool* redo) {
+  *done = *redo = false;
+  const int Bt = mb.sb + mb.dbits + 1;
+  static const int tiles_env = [] { const char* e = getenv("SHZ_VOTE_TILES"); return e ? atoi(e) : -1; }();
+  static const int force32 = [] { const char* e = getenv("SHZ_VOTE32"); return e ? atoi(e) : -1; }();   // 0 never, 1 whenever it fits
+  if (tiles_env == 0 || force32 == 0 || Bt > 31 || topn > VT_MAXTOPN || mb.dbits > VT_MAX_DBITS + VT_MAX_DSPLIT) return SHZ_OK;
+  if (force32 != 1 && n < (1ull << 22)) return SHZ_OK;   // few votes: the passes' launches cost more than the full sort's extra bytes
+  // 1. by query (stable: the order inside a query does not matter to the tiles)
+  int sel = 0;
+  if (mb.qb > 0) SHZ_TRY(shz_sort_u64(ctx, d_pairs, d_alt, nullptr, nullptr, 0, n, Bt, Bt + mb.qb, &sel));
+  const uint64_t* sorted = sel ? d_alt : d_pairs;
+  // 2. votes per query
+  void *qs, *flag;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M0, ((uint64_t)nq + 1) * 8, &qs));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M1, 64, &flag));
+  SHZ_HIP(ctx, hipMemsetAsync(flag, 0, 64, ctx->stream));
+  hipLaunchKernelGGL(pv_qstart_kernel, dim3(nblk((uint64_t)nq + 1)), dim3(256), 0, ctx->stream, sorted, n, Bt, nq,
+                     (unsigned long long*)qs);
+  SHZ_HIP(ctx, hipGetLastError());
+  std::vector<uint64_t> h_qs((size_t)nq + 1);
+  SHZ_HIP(ctx, shz_memcpy(ctx, h_qs.data(), qs, ((uint64_t)nq + 1) * 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // 3. 4-byte votes; the other half of the buffer is the sort's second one
+  void* kb;
+  const uint64_t n4 = (n + 3) & ~3ull;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_C, (n4 * 2) * 4 + 64, &kb));
+  uint32_t* k32 = (uint32_t*)kb;
+  hipLaunchKernelGGL(pv_narrow_kernel, dim3((unsigned)std::min<uint64_t>(nblk(n), 65536)), dim3(256), 0, ctx->stream, sorted, n,
+                     (uint32_t)((1ull << Bt) - 1ull), k32);
+  SHZ_HIP(ctx, hipGetLastError());
+  // 4. passes of up to VT_MAXQ queries and 2^28 votes
+  m_bits mbp = mb;
+  mbp.qb = 0;
+  const uint64_t P_PASS = 1ull << 28;
+  for (uint32_t qa = 0; qa < nq;) {
+    uint32_t qb = qa;
+    while (qb < nq && qb - qa < (uint32_t)VT_MAXQ && (qb == qa || h_qs[qb + 1] - h_qs[qa] <= P_PASS)) ++qb;
+    const uint64_t v_lo = h_qs[qa], pp = h_qs[qb] - v_lo;
+    if (pp >= (1ull << 32)) return SHZ_OK;   // (one query with 2^32 votes: the full sort's error message)
+    if (pp) {
+      const uint32_t nqp = qb - qa;
+      std::vector<uint64_t> counts(nqp);
+      for (uint32_t i = 0; i < nqp; ++i) counts[i] = h_qs[qa + i + 1] - h_qs[qa + i];
+      vt_plan pl;
+      shz_seg_plan sp;
+      vt_make_plan(counts.data(), nqp, mbp, pl, sp);
+      // the pass sorts inside [v_lo, v_lo + pp) of k32 and of the second buffer; both offsets 16-byte aligned by address
+      // is not required (the counting kernel aligns by address)
+      SHZ_TRY(vt_run_pass(ctx, k32 + v_lo, k32 + n4 + v_lo, pp, pl, sp, mbp, topn, false, mb.sb >= 31 ? 0x7FFFFFFFu : (1u << mb.sb),
+                          (uint32_t*)flag, r_sid + (uint64_t)qa * topn, r_delta + (uint64_t)qa * topn, r_al + (uint64_t)qa * topn,
+                          r_dd + (uint64_t)qa * topn, r_n + qa));
+    }
+    qa = qb;
+  }
+  uint32_t h_flag = 0;
+  SHZ_HIP(ctx, shz_memcpy(ctx, &h_flag, flag, 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_flag) { ++ctx->st_vt_redo; *redo = true; return SHZ_OK; }
+  *done = true;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, uint32_t n_queries, uint32_t sid_bits,
                                   uint32_t delta_bits, uint32_t bias, uint32_t topn, uint32_t* out_sid, int32_t* out_delta,
                                   uint32_t* out_aligned, uint32_t* out_dedup, uint32_t* out_nres) {
@@ -2455,8 +2542,20 @@ extern "C" int32_t shz_pairs_vote(shz_ctx* ctx, uint64_t* d_pairs, uint64_t n, u
   SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
   SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)n_queries * 4, ctx->stream));
-  SHZ_TRY(vote_tail(ctx, d_pairs, (uint64_t*)v1, n, n_queries, mb, topn, (uint64_t*)tot, (uint32_t*)r_sid, (int32_t*)r_delta,
-                    (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
+  bool done = false, redo = false;
+  SHZ_TRY(pairs_vote_tiles(ctx, d_pairs, (uint64_t*)v1, n, n_queries, mb, topn, (uint32_t*)r_sid, (int32_t*)r_delta, (uint32_t*)r_al,
+                           (uint32_t*)r_dd, (uint32_t*)r_n, &done, &redo));
+  if (redo) {   // a tile gave up: its rows of the result arrays are void
+    SHZ_HIP(ctx, hipMemsetAsync(r_sid, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_delta, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_al, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_dd, 0, nres * 4, ctx->stream));
+    SHZ_HIP(ctx, hipMemsetAsync(r_n, 0, (uint64_t)n_queries * 4, ctx->stream));
+  }
+  // (the full sort orders any permutation of the votes: whatever the sort by query left in d_pairs / v1 is fine for it)
+  if (!done)
+    SHZ_TRY(vote_tail(ctx, d_pairs, (uint64_t*)v1, n, n_queries, mb, topn, (uint64_t*)tot, (uint32_t*)r_sid, (int32_t*)r_delta,
+                      (uint32_t*)r_al, (uint32_t*)r_dd, (uint32_t*)r_n));
   SHZ_HIP(ctx, shz_memcpy(ctx, out_sid, r_sid, nres * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, shz_memcpy(ctx, out_delta, r_delta, nres * 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, shz_memcpy(ctx, out_aligned, r_al, nres * 4, hipMemcpyDeviceToHost));
