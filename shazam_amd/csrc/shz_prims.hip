@@ -259,10 +259,18 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t*
     ulonglong2 x[SORT_ROUNDS / 2];
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) x[r] = k2[r * SORT_THREADS + threadIdx.x];
+    // keys that arrive clustered on this digit (votes grouped by shard and query, sorted on their query bits; rows of one
+    // song sorted on their song bits) put all 64 lanes of a wave on ONE counter, which the LDS then serves one lane at a
+    // time: a wave whose lanes agree adds 64 once
+    auto count = [&](uint32_t d) {
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+      if (__ballot(d != d0) == 0ull) { if ((threadIdx.x & 63) == 0) atomicAdd(&h[d0], 64u); }
+      else atomicAdd(&h[d], 1u);
+    };
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS / 2; ++r) {
-      atomicAdd(&h[(x[r].x >> shift) & dmask], 1u);
-      atomicAdd(&h[(x[r].y >> shift) & dmask], 1u);
+      count((uint32_t)(x[r].x >> shift) & dmask);
+      count((uint32_t)(x[r].y >> shift) & dmask);
     }
   } else {
     for (int r = 0; r < SORT_ROUNDS; ++r) {
