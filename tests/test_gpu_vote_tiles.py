@@ -193,3 +193,15 @@ def test_vote_paths_agree_at_200k_songs():
             assert (fast["sid"][:, 0] == 1 + tids).mean() > 0.97
         for b in {id(b): b for b in qb}.values():
             b.free()
+
+
+def test_fuzz_and_schema_suites_under_forced_4_byte_votes():
+    """The randomized differential test of the match (many table shapes incl. several segments, hot keys, empty queries)
+    and the match golden tests, once more in a child process with SHZ_VOTE32=1: every pass whose layout fits takes the
+    4-byte votes, the expand by sort blocks and the vote tiles, however few votes it has."""
+    env = dict(os.environ, SHZ_VOTE32="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_match_fuzz.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_match.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
