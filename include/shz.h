@@ -214,13 +214,21 @@ int32_t shz_table_finalize(shz_table* t);
  * shz_table_reserve announces how many rows the table will hold and how many arrive between two seals; ONE slab for
  * the segments' columns, the run arena, the staging columns and the sort scratch are then allocated once, on a helper
  * thread beside the first fingerprint batches, and the build performs no further device allocation.  Without it
- * everything still works, allocating as it goes.  rows_hint = 0: no-op.  flags: SHZ_RESERVE_GATHER, SHZ_RESERVE_WAIT.
- * shz_table_seal_run turns the staged rows into a sorted run (bounded scratch: one batch) WITHOUT making them visible
- * to queries; full segments are cut as soon as enough rows wait; shz_table_finalize merges what is left (k-way merge of
- * the runs, 8 bytes read + 12 written per row) and makes everything visible.  On a table whose active segment holds
- * rows, or whose song ids + offsets need more than 32 bits, seal_run is finalize. */
+ * everything still works, allocating as it goes.  flags: SHZ_RESERVE_WAIT (return when the memory is there),
+ * SHZ_RESERVE_GATHER: the table HOLDS its sealed runs in the arena (sized for all rows_hint rows, this rank's and its
+ * peers') until shz_table_finalize / shz_table_allgather merges all of them at once -- seal_run never cuts a segment on
+ * the way, so every row can still travel, and the one merge cuts segments by KEY RANGE (a query hash is then looked up
+ * in one segment, not in all).  The flag takes effect with rows_hint = 0 too (nothing is allocated ahead then).
+ * shz_table_seal_run turns the staged rows into a sorted run (bounded scratch: one batch; more than 2^32 - 4096 staged
+ * rows become several runs) WITHOUT making them visible to queries.  Without SHZ_RESERVE_GATHER full segments are cut as
+ * soon as enough rows wait (bounded arena).  shz_table_finalize merges what is left (k-way merge of the runs, 8 bytes
+ * read + 12 written per row) and makes everything visible.  On a table whose active segment holds rows, or whose song
+ * ids + offsets need more than 32 bits, seal_run is finalize -- on a table that holds its runs it is SHZ_E_UNSUPPORTED
+ * instead and the rows stay staged (rows put into segments could not travel any more). */
 int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t batch_rows_hint, uint32_t flags);
 int32_t shz_table_seal_run(shz_table* t);
+/* rows one sealed run may hold (0 = the limit of a radix sort, 2^32 - 4096); small values make many runs of few rows (tests) */
+int32_t shz_table_set_run_rows(shz_table* t, uint64_t rows);
 /* A table is a list of sorted segments (each one radix sort, < 2^32 rows) that every probe visits; rows
  * beyond `rows` per segment open a new one at finalize.  Default 2^31; smaller values only for tests.
  * UNIQUE(song_id, offset, hash) + INSERT IGNORE (mysql_database.py:54-55, 62-68) hold across segments: staged rows
@@ -278,7 +286,7 @@ int32_t shz_match_stats(shz_ctx* ctx, uint64_t* rows_scanned, uint64_t* pairs, u
 
 /* ---- multi-GPU database build (new) ---------------------------------------- */
 /* RCCL communicator, one rank per GPU.  id: 128-byte ncclUniqueId made by rank 0 and shipped
- * to the other ranks by the host (torch.distributed / any store). */
+ * to the other ranks by the host (a file, a socket, any key-value store the launcher offers). */
 int32_t shz_comm_unique_id(uint8_t id_out[128]);
 int32_t shz_comm_create(shz_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t nranks, shz_comm** out);
 /* The same communicator interface with the ranks as THREADS of one process (one context each, on one device or on several):
@@ -286,19 +294,38 @@ int32_t shz_comm_create(shz_ctx* ctx, const uint8_t id[128], int32_t rank, int32
  * one-GPU box (tests), and a single process drive several GPUs without RCCL.  group_id: any number the ranks agree on. */
 int32_t shz_comm_create_local(shz_ctx* ctx, uint64_t group_id, int32_t rank, int32_t nranks, shz_comm** out);
 int32_t shz_comm_destroy(shz_comm* c);
-/* All-gather every rank's STAGED rows over RCCL/xGMI into the node-global table: afterwards every rank holds the
- * same table.  Into an empty table (the database build) every rank sorts its own rows, the sorted runs travel packed
- * at 8 bytes a row in pieces of <= 1 GB (SHZ_ALLGATHER=sendrecv (default, explicit mesh) | bcast selects the
- * pattern), and every rank merges the nranks runs (log2 nranks merge-path passes) and cuts segments -- no rank sorts
- * other ranks' rows again.  Otherwise (table not empty, or song id + offset wider than 32 bits, or
- * SHZ_ALLGATHER=columns) the unsorted columns travel and finalize sorts everything.
- * bytes_recv: payload bytes this rank received. */
+/* The gathered build (the reference's analogue is the pool + insert loop of fingerprint_directory,
+ * __init__.py:341, 357-386, which overlaps fingerprinting of the next song with the insert of the last).
+ * Collective calls: every rank of the communicator makes them, on tables reserved with SHZ_RESERVE_GATHER.
+ *
+ * shz_table_exchange_run: the staged rows become a sorted run (as shz_table_seal_run) and ONE exchange round runs: all
+ *   ranks all-gather a 320-byte block (largest song id / offset so far, flags, row counts and song-id ranges of the runs
+ *   they have sealed and not yet sent -- up to 16 a round, each < 2^32 rows), agree on one packing layout from the global
+ *   maxima, and every rank's announced runs start travelling to every peer, 8 bytes a row in pieces of <= 1 GB, each
+ *   pair of GPUs on its own xGMI link (grouped ncclSend / ncclRecv), on the communicator's own stream: the call returns
+ *   with the transfers in flight, and the next batch is fingerprinted beside them.  Ranks need not call it equally often.
+ * shz_table_allgather: seals what is staged, runs rounds until every rank has arrived here and sent all its runs, waits
+ *   for the transfers, and merges ALL runs -- its own and its peers' -- in one k-way merge into segments cut by key range
+ *   (more than 32 runs: the smallest are merged first).  No rank sorts another rank's rows.  Afterwards every rank
+ *   holds the same table.  Which rows travel: everything inserted since the table was last finalized / gathered --
+ *   staged rows and sealed runs.
+ * The column path: when any rank's table already holds rows, or its song ids + offsets need more than 32 bits, or
+ *   SHZ_ALLGATHER=columns is set, the ranks' STAGED rows travel as unsorted columns and finalize sorts them into the
+ *   table each rank holds.  Every rank takes it if any rank needs it.  Sealed runs do not travel on it: if any rank
+ *   holds one, or its seal_run has already moved rows into segments (a table not reserved with SHZ_RESERVE_GATHER that
+ *   sealed past a segment's worth), EVERY rank returns SHZ_E_STATE -- never a table that differs between ranks.
+ * bytes_recv: payload bytes this rank received (all rounds of this build). */
+int32_t shz_table_exchange_run(shz_table* t, shz_comm* c);
 int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* bytes_recv);
+/* exchange rounds / payload bytes received / host seconds spent waiting for peers and transfers since the last
+ * shz_table_allgather, and the runs the arena holds now.  Any pointer may be NULL. */
+int32_t shz_table_exchange_stats(shz_table* t, uint64_t* rounds, uint64_t* bytes_recv, double* wait_s, uint32_t* runs_held);
 /* The sort + merge + segments half of the above without a communicator: the staged rows are n_runs consecutive
  * blocks of run_rows[r] rows (what n_runs ranks would have staged); the result equals shz_table_finalize's. */
 int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_rows, uint32_t n_runs);
-/* seconds the last shz_table_allgather / shz_table_finalize_runs spent sorting its own rows, exchanging, merging
- * the runs and cutting segments (host clock around stream syncs).  Any pointer may be NULL. */
+/* seconds the last shz_table_allgather / shz_table_finalize_runs spent sorting its own rows, inside exchange rounds
+ * (host time: waiting for peers and for transfers, queueing them -- with pipelined rounds most of a transfer runs beside
+ * fingerprinting and shows up nowhere), merging the runs and cutting segments.  Any pointer may be NULL. */
 int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, double* merge_s, double* segments_s);
 /* Host seconds the table spent per phase of the build since the last reset (stream drained at each phase border):
  * staging allocation, insert, INSERT-IGNORE anti-join against frozen segments, segment top-up, maxima, sort, merge,

@@ -84,6 +84,9 @@ SIGNATURES = {
     "shz_comm_create_local": (C.c_int32, [vp, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "shz_comm_destroy": (C.c_int32, [vp]),
     "shz_table_allgather": (C.c_int32, [vp, vp, u64p]),
+    "shz_table_exchange_run": (C.c_int32, [vp, vp]),
+    "shz_table_exchange_stats": (C.c_int32, [vp, u64p, u64p, C.POINTER(C.c_double), u32p]),
+    "shz_table_set_run_rows": (C.c_int32, [vp, C.c_uint64]),
     "shz_table_finalize_runs": (C.c_int32, [vp, u64p, C.c_uint32]),
     "shz_table_build_stats": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
@@ -503,7 +506,8 @@ class Table:
 
     def reserve(self, rows_hint: int, batch_rows_hint: int = 0, gather: bool = False, wait: bool = False):
         """Announce the size of a bulk build: the table's arenas are allocated once, beside the first batches (wait: before
-        this call returns)."""
+        this call returns).  gather: the table holds its sealed runs until finalize() / allgather() merges them all at once
+        (what a gathered build needs -- every row can still travel -- and what cuts segments by key range)."""
         self.ctx.check(lib().shz_table_reserve(self.h, int(rows_hint), int(batch_rows_hint),
                                                (RESERVE_GATHER if gather else 0) | (RESERVE_WAIT if wait else 0)))
 
@@ -575,7 +579,23 @@ class Table:
         self.ctx.check(lib().shz_table_phase_stats(self.h, v, n.value, C.byref(n), 1 if reset else 0))
         return {lib().shz_table_phase_name(i).decode(): float(v[i]) for i in range(n.value)}
 
+    def set_run_rows(self, rows: int):
+        """Rows one sealed run may hold (0: 2^32 - 4096); small values force many runs (tests)."""
+        self.ctx.check(lib().shz_table_set_run_rows(self.h, int(rows)))
+
+    def exchange_run(self, comm: "Comm"):
+        """Collective: seal the staged rows and start this round's runs travelling to every peer on the communicator's own
+        stream; returns with the transfers in flight (the next batch is fingerprinted beside them)."""
+        self.ctx.check(lib().shz_table_exchange_run(self.h, comm.h))
+
+    def exchange_stats(self) -> dict:
+        r, b, w, k = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_uint32()
+        self.ctx.check(lib().shz_table_exchange_stats(self.h, C.byref(r), C.byref(b), C.byref(w), C.byref(k)))
+        return {"rounds": r.value, "bytes_received": b.value, "wait_s": w.value, "runs_held": k.value}
+
     def allgather(self, comm: "Comm") -> int:
+        """Collective: seal what is staged, exchange every run not yet sent, merge all runs into the node-global table;
+        returns the payload bytes this rank received."""
         b = C.c_uint64()
         self.ctx.check(lib().shz_table_allgather(self.h, comm.h, C.byref(b)))
         return b.value

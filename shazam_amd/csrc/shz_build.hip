@@ -173,6 +173,7 @@ __global__ void tbl_slice_scatter_kernel(const uint32_t* __restrict__ key, const
 static void reserve_wait(shz_table* t, int which);
 static int32_t seal_staged(shz_table* t, const uint64_t* block_rows, uint32_t n_blocks, bool* packed);
 static int32_t flush_runs(shz_table* t, bool final);
+static uint64_t runs_end(const shz_table* t);
 static int32_t staged_minmax(shz_table* t, uint64_t lo, uint64_t n, uint32_t out[3]);
 static void reserve_cancel(shz_table* t);
 
@@ -196,6 +197,9 @@ extern "C" int32_t shz_table_destroy(shz_table* t) {
   if (!t) return SHZ_E_INVALID;
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
+  if (t->gx_stream) (void)hipStreamSynchronize(t->gx_stream);
+  if (t->d_kw_err) (void)hipFree(t->d_kw_err);
+  if (t->gx_ev) (void)hipEventDestroy(t->gx_ev);
   reserve_cancel(t);
   free_cols(t->act_slab, t->key, t->sid, t->off);
   if (t->stage_reserved) {
@@ -661,6 +665,7 @@ extern "C" int32_t shz_table_clear(shz_table* t) {
   shz_ctx* ctx = t->ctx;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (t->gx_stream) SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));
   for (shz_seg& g : t->done) {
     free_cols(g.slab, g.key, g.sid, g.off);
     if (g.bucket) (void)hipFree(g.bucket);
@@ -668,6 +673,9 @@ extern "C" int32_t shz_table_clear(shz_table* t) {
   t->done.clear();
   t->runs.clear();
   t->run_sb = t->run_ob = 0;
+  t->rows_cut = t->gx_recv_bytes = t->gx_rounds = 0;
+  t->gx_wait_s = t->gx_xfer_s = 0.0;
+  t->hold_runs = t->hold_reserved;
   if (t->act_slab) { t->key = t->sid = t->off = nullptr; t->cap = 0; t->act_slab = false; }   // the slab starts over: nothing is carved
   t->slab_used = 0;
   t->act_sid_lo = 0xFFFFFFFFu;
@@ -1045,7 +1053,7 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
 
 #define SHZ_I_GENERAL_PATH 1   // internal: the packed sorted-run path does not apply, take the column path
 
-#define KW_MAXK 16             // runs one merge takes (more: the oldest are merged into one first)
+#define KW_MAXK 32             // runs one merge takes (more: the smallest are merged into one first)
 #define KW_THREADS 256
 #define KW_TILE 2048           // nominal rows of a tile = samples per tile x sample stride
 #define KW_TMAX (3 * KW_TILE)  // a tile holds fewer than (c + 2 k) M <= 3 c M rows (c samples per tile >= k runs, stride M)
@@ -1053,7 +1061,7 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
 
 struct kw_runs {
   const uint64_t* p[KW_MAXK];
-  uint32_t n[KW_MAXK];
+  uint64_t n[KW_MAXK];          // a run may hold more than 2^32 rows (a rank's collapsed runs at BASELINE configs[4])
   uint32_t soff[KW_MAXK + 1];   // first sample of every run in the sample array
   uint32_t k;
 };
@@ -1074,6 +1082,7 @@ struct shz_reserve_job {
   uint32_t* st[3] = {nullptr, nullptr, nullptr};
   uint64_t* rbuf = nullptr;
   void* sortbuf[2] = {nullptr, nullptr};
+  int n_sort = 2;
   char* slab = nullptr;
   bool failed = false;
   double alloc_s = 0.0;          // seconds the helper thread spent inside hipMalloc
@@ -1093,8 +1102,8 @@ static void reserve_worker(shz_reserve_job* j) {
   if (!ok) { for (int i = 0; i < 3; ++i) { if (j->st[i]) shz_block_free(j->ctx, j->st[i], j->st_bytes[i]); j->st[i] = nullptr; } (void)hipGetLastError(); }
   step(RJ_STAGE);
   if (j->run_rows && shz_block_alloc(j->ctx, j->run_rows * 8, (void**)&j->rbuf, &j->rbuf_bytes) != hipSuccess) { j->rbuf = nullptr; (void)hipGetLastError(); }
-  for (auto& q : j->sortbuf)
-    if (j->sort_bytes && hipMalloc(&q, j->sort_bytes) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+  for (int i = 0; i < j->n_sort; ++i)
+    if (j->sort_bytes && hipMalloc(&j->sortbuf[i], j->sort_bytes) != hipSuccess) { j->sortbuf[i] = nullptr; (void)hipGetLastError(); }
   step(RJ_RUNS);
   if (j->slab_bytes) {
     const uint64_t want = j->slab_bytes;
@@ -1151,6 +1160,7 @@ static void reserve_wait(shz_table* t, int which) {
 extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t batch_rows_hint, uint32_t flags) {
   if (!t) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
+  if (flags & SHZ_RESERVE_GATHER) t->hold_runs = t->hold_reserved = true;   // (also without a row count: the runs wait, the arena grows as it must)
   if (t->job || t->slab) return SHZ_OK;   // one reservation per table
   if (rows_hint == 0) return SHZ_OK;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -1163,14 +1173,15 @@ extern "C" int32_t shz_table_reserve(shz_table* t, uint64_t rows_hint, uint64_t 
   // run arena: what is merged at once.  One GPU: a segment's worth of runs + the batch being sealed + the remainder a
   // flush leaves; the gathered build (SHZ_RESERVE_GATHER): this rank's run beside every rank's.
   const uint64_t seg = std::min<uint64_t>(rows_hint, t->seg_limit);
-  j->run_rows = (flags & SHZ_RESERVE_GATHER) ? rows_hint + batch_rows_hint + batch_rows_hint / 8 + 65536
+  j->run_rows = (flags & SHZ_RESERVE_GATHER) ? rows_hint + rows_hint / 64 + batch_rows_hint + batch_rows_hint / 8 + 65536
                                              : seg + 2 * (batch_rows_hint + batch_rows_hint / 16) + 65536;
   j->sort_bytes = (batch_rows_hint + batch_rows_hint / 16 + 65536) * 8;
+  j->n_sort = (flags & SHZ_RESERVE_GATHER) ? 1 : 2;   // (the second scratch holds what a mid-build flush leaves over: never with held runs)
   // columns: 12 bytes a row, 256-byte aligned per column, + 2 % for duplicates-free estimates that run a little over
   j->slab_bytes = ((rows_hint + rows_hint / 50 + 65536) * 12 + 4095) & ~4095ull;
   size_t mem_free = 0, mem_total = 0;
   SHZ_HIP(ctx, hipMemGetInfo(&mem_free, &mem_total));
-  const uint64_t want = j->slab_bytes + j->run_rows * 8 + j->stage_rows * 12 + 2 * j->sort_bytes;
+  const uint64_t want = j->slab_bytes + j->run_rows * 8 + j->stage_rows * 12 + j->n_sort * j->sort_bytes;
   uint64_t avail = mem_free;   // + what the context keeps from earlier tables (reused where it fits, dropped where it does not)
   {
     std::lock_guard<std::mutex> lk(ctx->blocks_mu);
@@ -1213,6 +1224,7 @@ static int32_t rbuf_reserve(shz_table* t, uint64_t rows) {
   shz_ctx* ctx = t->ctx;
   reserve_wait(t, RJ_RUNS);
   if (rows <= t->rcap) return SHZ_OK;
+  if (t->gx_stream) SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));   // the arena moves: no transfer may be on its way into it
   uint64_t used = 0;
   for (const shz_run& r : t->runs) used = std::max(used, r.off + r.n);
   const uint64_t cap = std::max<uint64_t>(rows + rows / 8 + 1024, 1024);
@@ -1301,26 +1313,26 @@ __global__ void kw_sample_kernel(kw_runs R, uint32_t M, uint64_t* __restrict__ o
 // bounds[t * k + r] = first element of run r that belongs to tile t or a later one: tile t takes the values
 // [smp[t * c], smp[(t + 1) * c)), the first tile everything below, the last everything above
 __global__ void kw_bounds_kernel(kw_runs R, const uint64_t* __restrict__ smp, uint32_t c, uint32_t ntiles,
-                                 uint32_t* __restrict__ bounds) {
+                                 uint64_t* __restrict__ bounds) {
   const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = R.k;
   if (e >= ((uint64_t)ntiles + 1) * k) return;
   const uint32_t t = (uint32_t)(e / k), r = (uint32_t)(e - (uint64_t)t * k);
-  uint32_t lo = 0, hi = R.n[r];
+  uint64_t lo = 0, hi = R.n[r];
   if (t == 0) hi = 0;
   else if (t == ntiles) lo = hi;
   else {
     const uint64_t v = smp[(uint64_t)t * c];
     const uint64_t* __restrict__ p = R.p[r];
     while (lo < hi) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const uint64_t mid = lo + ((hi - lo) >> 1);
       if (p[mid] < v) lo = mid + 1; else hi = mid;
     }
   }
   bounds[e] = lo;
 }
 
-__global__ void kw_tile_rows_kernel(const uint32_t* __restrict__ bounds, uint32_t k, uint32_t ntiles, uint64_t* __restrict__ rows) {
+__global__ void kw_tile_rows_kernel(const uint64_t* __restrict__ bounds, uint32_t k, uint32_t ntiles, uint64_t* __restrict__ rows) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > ntiles) return;
   uint64_t s = 0;
@@ -1356,17 +1368,23 @@ __global__ void kw_cuts_kernel(const uint64_t* __restrict__ base, uint32_t ntile
 // dropped; 3: rows -> packed; 4: packed, duplicates dropped.  base[t] = output row of tile t (of the distinct rows in
 // the modes that drop duplicates); this launch writes relative to row out0.
 template <int MODE>
-__global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const uint32_t* __restrict__ bounds, uint32_t tile0,
+__global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const uint64_t* __restrict__ bounds, uint32_t tile0,
                                                              const uint64_t* __restrict__ base, uint64_t out0, int sb, int ob,
                                                              uint32_t* __restrict__ okey, uint32_t* __restrict__ osid,
                                                              uint32_t* __restrict__ ooff, uint64_t* __restrict__ opacked,
-                                                             uint64_t* __restrict__ uniq) {
+                                                             uint64_t* __restrict__ uniq, uint32_t* __restrict__ err) {
   __shared__ uint64_t buf[KW_TMAX];
-  __shared__ uint32_t s_lo[KW_MAXK], s_off[KW_MAXK + 1], s_w[KW_THREADS / 64 + 1];
+  __shared__ uint64_t s_lo[KW_MAXK];
+  __shared__ uint32_t s_off[KW_MAXK + 1], s_w[KW_THREADS / 64 + 1];
   const uint32_t t = tile0 + blockIdx.x, k = R.k, tid = threadIdx.x, lane = tid & 63;
   if (tid < 64) {
-    uint32_t lo = 0, cnt = 0;
-    if (tid < k) { lo = bounds[(uint64_t)t * k + tid]; cnt = bounds[(uint64_t)(t + 1) * k + tid] - lo; }
+    uint64_t lo = 0;
+    uint32_t cnt = 0;
+    if (tid < k) {
+      lo = bounds[(uint64_t)t * k + tid];
+      const uint64_t c64 = bounds[(uint64_t)(t + 1) * k + tid] - lo;
+      cnt = (uint32_t)(c64 < 0x7FFFFFFull ? c64 : 0x7FFFFFFull);   // (a share that large has broken the plan: flagged below)
+    }
     uint32_t inc = cnt;
 #pragma unroll
     for (int d = 1; d < KW_MAXK; d <<= 1) {
@@ -1377,7 +1395,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
     if (tid == 0) s_off[0] = 0;
   }
   __syncthreads();
-  const uint32_t total = min(s_off[k], (uint32_t)KW_TMAX);   // (the bound holds by construction; the clamp keeps a wrong plan from writing past buf)
+  // The plan bounds a tile below KW_TMAX rows.  Should it ever not, the tile says so: the host fails the merge and
+  // marks the table (rows beyond the clamp would be lost, the columns would hold holes) -- never a silent drop.
+  if (s_off[k] > (uint32_t)KW_TMAX && tid == 0) atomicOr(err, 1u);
+  const uint32_t total = min(s_off[k], (uint32_t)KW_TMAX);
   for (uint32_t r = 0; r < k; ++r) {
     const uint64_t* __restrict__ p = R.p[r] + s_lo[r];
     const uint32_t o = s_off[r], c = min(s_off[r + 1], total) - min(o, total);
@@ -1483,20 +1504,20 @@ static uint64_t runs_rows(const shz_table* t) {
   return n;
 }
 
-// the layout every run of the table is packed in: fixed by the first run (all spare bits to the song id, which grows
-// with ingest), widened -- existing runs repacked in place -- when a later batch brings longer tracks.  false: ids and
-// offsets do not fit 32 bits together.
+// The layout every run of the table is packed in is a PURE function of the largest offset the table has seen:
+// ob = its bits, sb = 32 - ob (all spare bits to the song id, which grows with ingest).  Widening -- a later batch
+// brings longer tracks -- repacks the runs the arena holds in place (monotone: sorted runs stay sorted).  Being pure,
+// the ranks of a gathered build arrive at the same layout from the same global maxima, whatever each sealed before.
+// false: ids and offsets do not fit 32 bits together.
 static int32_t run_layout(shz_table* t, uint32_t max_sid, uint32_t max_off, bool* ok) {
   shz_ctx* ctx = t->ctx;
   const int need_sb = bits_for(max_sid), need_ob = bits_for(max_off);
-  *ok = need_sb + need_ob <= 32;
+  const int ob = std::max(need_ob, t->run_ob), sb = 32 - ob;   // (run_ob only grows: it covers everything packed so far)
+  *ok = need_sb + ob <= 32;
   if (!*ok) return SHZ_OK;
-  if (t->run_ob && need_sb <= t->run_sb && need_ob <= t->run_ob) return SHZ_OK;
-  int ob = need_ob, sb = 32 - need_ob;
+  if (ob == t->run_ob) return SHZ_OK;
   if (t->run_ob && !t->runs.empty()) {
-    // what the existing runs hold must still fit: their layout's fields are upper bounds
-    ob = std::max(need_ob, std::min(t->run_ob, 32 - need_sb));
-    sb = 32 - ob;
+    if (t->gx_stream) SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));   // no transfer touches a run while it is rewritten
     for (const shz_run& r : t->runs)
       if (r.n)
         hipLaunchKernelGGL(run_repack_kernel, dim3((unsigned)std::min<uint64_t>((r.n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
@@ -1574,7 +1595,8 @@ static bool runs_may_share_rows(const std::vector<shz_run>& runs) {
 // The k-way merge of `runs` (pointers into device memory, each sorted and duplicate-free).  Output pieces of at most
 // `piece_rows` rows: the first `n_seg_pieces` of them (all if 0xFFFFFFFF) become table segments -- the last one the
 // active segment when `last_active` --, what is left is written packed to `rest` (capacity rest_cap rows) and its
-// row count to *rest_rows.  dedup: rows may repeat across runs.
+// row count to *rest_rows.  dedup: rows may repeat across runs.  Pieces follow each other in value order: the segments
+// of one merge hold disjoint key ranges (but for a key whose rows straddle a cut).
 static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr, const std::vector<shz_run>& runs, bool dedup,
                           uint64_t piece_rows, uint32_t n_seg_pieces, bool last_active, uint64_t* rest, uint64_t rest_cap,
                           uint64_t* rest_rows) {
@@ -1587,7 +1609,7 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     if (!runs[i].n) continue;
     if (k == KW_MAXK) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "k-way merge of more than %d runs", KW_MAXK);
     R.p[k] = ptr[i];
-    R.n[k] = (uint32_t)runs[i].n;
+    R.n[k] = runs[i].n;
     sid_lo = std::min(sid_lo, runs[i].sid_lo);
     sid_hi = std::max(sid_hi, runs[i].sid_hi);
     ++k;
@@ -1595,20 +1617,26 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
   if (k == 0) return SHZ_OK;
   R.k = k;
   ph_clock pc(t);
+  if (!t->d_kw_err) SHZ_HIP(ctx, hipMalloc(&t->d_kw_err, 64));
+  SHZ_HIP(ctx, hipMemsetAsync(t->d_kw_err, 0, 64, ctx->stream));
   // plan: every M-th element of every run is a sample; every c-th of the sorted samples starts a tile
   uint32_t kp2 = 1;
   while (kp2 < k) kp2 <<= 1;
   const uint32_t nominal = (uint32_t)std::min<uint64_t>(KW_TILE, std::max<uint64_t>(kp2, piece_rows / 8));
   const uint32_t M = std::max<uint32_t>(1, nominal / kp2), c = kp2;
   uint64_t S = 0;
-  for (uint32_t r = 0; r < k; ++r) { R.soff[r] = (uint32_t)S; S += (R.n[r] + M - 1) / M; }
+  for (uint32_t r = 0; r < k; ++r) {
+    if (S >= (1ull << 32)) break;
+    R.soff[r] = (uint32_t)S;
+    S += (R.n[r] + M - 1) / M;
+  }
   if (S >= (1ull << 32)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "k-way merge: %llu samples", (unsigned long long)S);
   R.soff[k] = (uint32_t)S;
   const uint32_t ntiles = (uint32_t)((S + c - 1) / c);
   void *smp0, *smp1, *bnd, *rows, *base, *cutp;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M2, S * 8, &smp0));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M3, S * 8, &smp1));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, ((uint64_t)ntiles + 1) * k * 4, &bnd));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M4, ((uint64_t)ntiles + 1) * k * 8, &bnd));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M5, ((uint64_t)ntiles + 1) * 8, &rows));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_M6, ((uint64_t)ntiles + 1) * 8, &base));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, sizeof(kw_cutlist), &cutp));
@@ -1618,16 +1646,16 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
   if (k > 1) SHZ_TRY(shz_sort_u64(ctx, (uint64_t*)smp0, (uint64_t*)smp1, nullptr, nullptr, 0, S, 0, 32 + t->run_sb + t->run_ob, &sel));
   const uint64_t* smp = sel ? (const uint64_t*)smp1 : (const uint64_t*)smp0;
   hipLaunchKernelGGL(kw_bounds_kernel, dim3(nblk(((uint64_t)ntiles + 1) * k)), dim3(256), 0, ctx->stream, R, smp, c, ntiles,
-                     (uint32_t*)bnd);
+                     (uint64_t*)bnd);
   const int sb = t->run_sb, ob = t->run_ob;
+  const uint64_t* cb = (const uint64_t*)bnd;
   if (!dedup) {
-    hipLaunchKernelGGL(kw_tile_rows_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, (const uint32_t*)bnd, k, ntiles,
-                       (uint64_t*)rows);
+    hipLaunchKernelGGL(kw_tile_rows_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, cb, k, ntiles, (uint64_t*)rows);
   } else {   // a first pass over the tiles counts their distinct rows
     SHZ_HIP(ctx, hipMemsetAsync((uint64_t*)rows + ntiles, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(kw_tile_kernel<1>, dim3(ntiles), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, 0u,
+    hipLaunchKernelGGL(kw_tile_kernel<1>, dim3(ntiles), dim3(KW_THREADS), 0, ctx->stream, R, cb, 0u,
                        (const uint64_t*)nullptr, (uint64_t)0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                       (uint64_t*)nullptr, (uint64_t*)rows);
+                       (uint64_t*)nullptr, (uint64_t*)rows, t->d_kw_err);
   }
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)rows, (uint64_t*)base, (uint64_t)ntiles + 1, nullptr));
@@ -1641,6 +1669,19 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
   const uint64_t* cut_row = hc.row;
   if (n_cuts < 2 || cuts[n_cuts - 1] != ntiles) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
   pc.lap(PH_KW_PLAN);
+  // the tile kernels' verdict on the plan (a tile beyond KW_TMAX rows would have dropped rows): read after every launch
+  // of them has run, before anything is reported as done
+  auto check_tiles = [&]() -> int32_t {
+    uint32_t bad = 0;
+    SHZ_HIP(ctx, shz_memcpy(ctx, &bad, t->d_kw_err, 4, hipMemcpyDeviceToHost));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) {
+      t->broken = true;
+      SHZ_FAIL(ctx, SHZ_E_STATE, "k-way merge: a tile outgrew its bound of %d rows (k = %u, stride %u); the table is incomplete and refuses further use",
+               KW_TMAX, k, M);
+    }
+    return SHZ_OK;
+  };
   const uint32_t n_pieces = n_cuts - 1;
   const uint32_t n_seg = std::min(n_seg_pieces, n_pieces);
   if (t->done.size() + n_seg > SHZ_MAX_SEGS) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d table segments", SHZ_MAX_SEGS);
@@ -1654,11 +1695,11 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     SHZ_TRY(carve_cols(t, nrows, &ck, &cs, &co, &from_slab));
     pc.lap(PH_COL_ALLOC);
     if (dedup)
-      hipLaunchKernelGGL(kw_tile_kernel<2>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
-                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr);
+      hipLaunchKernelGGL(kw_tile_kernel<2>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
+                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
     else
-      hipLaunchKernelGGL(kw_tile_kernel<0>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
-                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr);
+      hipLaunchKernelGGL(kw_tile_kernel<0>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
+                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
     SHZ_HIP(ctx, hipGetLastError());
     // the new segment is the active one until the next piece (or the caller) freezes it
     if (t->key && !t->act_slab) { void* olds[] = {t->key, t->sid, t->off}; for (void* p : olds) (void)hipFree(p); }
@@ -1679,15 +1720,54 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     if (nrows > rest_cap || !rest) SHZ_FAIL(ctx, SHZ_E_STATE, "k-way merge: %llu rows left over, room for %llu", (unsigned long long)nrows, (unsigned long long)rest_cap);
     if (nrows) {
       if (dedup)
-        hipLaunchKernelGGL(kw_tile_kernel<4>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
-                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr);
+        hipLaunchKernelGGL(kw_tile_kernel<4>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
+                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
       else
-        hipLaunchKernelGGL(kw_tile_kernel<3>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, (const uint32_t*)bnd, t0, (const uint64_t*)base,
-                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr);
+        hipLaunchKernelGGL(kw_tile_kernel<3>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
+                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
       SHZ_HIP(ctx, hipGetLastError());
     }
     if (rest_rows) *rest_rows = nrows;
     pc.lap(PH_KW_MERGE);
+  }
+  return check_tiles();
+}
+
+// merge the smallest runs of the arena into one, at the arena's tail, until at most `keep` runs are left: a merge takes
+// KW_MAXK runs (the places the merged runs leave stay unused until the arena starts over)
+static int32_t collapse_runs(shz_table* t, size_t keep) {
+  keep = std::max<size_t>(keep, 1);
+  while (t->runs.size() > keep) {
+    const size_t m = std::min<size_t>(KW_MAXK, t->runs.size() - keep + 1);
+    std::vector<size_t> order(t->runs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return t->runs[a].n < t->runs[b].n; });
+    std::vector<size_t> pick(order.begin(), order.begin() + (long)m);
+    std::sort(pick.begin(), pick.end());
+    std::vector<shz_run> sub;
+    uint64_t total = 0;
+    uint32_t sid_lo = 0xFFFFFFFFu, sid_hi = 0;
+    uint8_t where = RUN_SENT;
+    for (size_t i : pick) {
+      const shz_run& r = t->runs[i];
+      sub.push_back(r);
+      total += r.n;
+      if (r.n) { sid_lo = std::min(sid_lo, r.sid_lo); sid_hi = std::max(sid_hi, r.sid_hi); }
+      if (r.where == RUN_LOCAL) where = RUN_LOCAL;   // (the exchange never collapses a mix of travelled and local runs)
+    }
+    const uint64_t tail = (runs_end(t) + 31) & ~31ull;
+    SHZ_TRY(rbuf_reserve(t, tail + total));
+    std::vector<const uint64_t*> ptr;
+    for (const shz_run& r : sub) ptr.push_back(t->rbuf + r.off);
+    uint64_t rest_rows = 0;
+    SHZ_TRY(kway_merge(t, ptr, sub, runs_may_share_rows(sub), ~0ull >> 1, 0, false, t->rbuf + tail, total, &rest_rows));
+    for (size_t j = pick.size(); j-- > 0;) t->runs.erase(t->runs.begin() + (long)pick[j]);
+    if (rest_rows) {
+      shz_run nr{tail, rest_rows, sid_lo, sid_hi};
+      nr.where = where;
+      t->runs.push_back(nr);
+    }
+    if (t->runs.empty()) break;
   }
   return SHZ_OK;
 }
@@ -1698,6 +1778,8 @@ static int32_t flush_runs(shz_table* t, bool final) {
   shz_ctx* ctx = t->ctx;
   uint64_t total = runs_rows(t);
   if (total == 0) { t->runs.clear(); return SHZ_OK; }
+  if (t->gx_stream) SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));   // every run has arrived
+  if (t->runs.size() > KW_MAXK) SHZ_TRY(collapse_runs(t, KW_MAXK));
   std::vector<const uint64_t*> ptr;
   for (const shz_run& r : t->runs) ptr.push_back(t->rbuf + r.off);
   const bool dedup = runs_may_share_rows(t->runs);
@@ -1708,6 +1790,7 @@ static int32_t flush_runs(shz_table* t, bool final) {
   if (final) {
     SHZ_TRY(kway_merge(t, ptr, t->runs, dedup, L, 0xFFFFFFFFu, true, nullptr, 0, nullptr));
     t->runs.clear();
+    t->hold_runs = false;   // the bulk build is over: rows that come now join a table that holds rows
     return SHZ_OK;
   }
   const uint32_t full = (uint32_t)(total / L);   // (duplicates across runs can only make the pieces fewer)
@@ -1721,30 +1804,6 @@ static int32_t flush_runs(shz_table* t, bool final) {
   t->runs.clear();
   if (rest_rows) {
     SHZ_TRY(rbuf_reserve(t, rest_rows));
-    SHZ_HIP(ctx, hipMemcpyAsync(t->rbuf, rest, rest_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    t->runs.push_back(shz_run{0, rest_rows, sid_lo, sid_hi});
-  }
-  return SHZ_OK;
-}
-
-// merge all runs of the arena into ONE run (more runs than a merge takes, or a rank about to send its rows)
-static int32_t collapse_runs(shz_table* t) {
-  shz_ctx* ctx = t->ctx;
-  if (t->runs.size() <= 1) return SHZ_OK;
-  const uint64_t total = runs_rows(t);
-  uint32_t sid_lo = 0xFFFFFFFFu, sid_hi = 0;
-  for (const shz_run& r : t->runs)
-    if (r.n) { sid_lo = std::min(sid_lo, r.sid_lo); sid_hi = std::max(sid_hi, r.sid_hi); }
-  if (total >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "a run is limited to < 2^32 rows (have %llu)", (unsigned long long)total);
-  std::vector<const uint64_t*> ptr;
-  for (const shz_run& r : t->runs) ptr.push_back(t->rbuf + r.off);
-  void* rest;
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_SORT_B, std::max<uint64_t>(total, 1) * 8, &rest));
-  uint64_t rest_rows = 0;
-  SHZ_TRY(kway_merge(t, ptr, t->runs, runs_may_share_rows(t->runs), (1ull << 32) - 4096, 0, false, (uint64_t*)rest, total, &rest_rows));
-  t->runs.clear();
-  if (rest_rows) {
     SHZ_HIP(ctx, hipMemcpyAsync(t->rbuf, rest, rest_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     t->runs.push_back(shz_run{0, rest_rows, sid_lo, sid_hi});
@@ -1769,9 +1828,15 @@ static int32_t staged_minmax(shz_table* t, uint64_t lo, uint64_t n, uint32_t out
   return SHZ_OK;
 }
 
-// The staged rows become one sorted run (blocks: several, one per block of block_rows[] rows).  *packed = false when
-// the packed form does not apply (ids + offsets wider than 32 bits, or the active segment holds rows): nothing was done,
-// the caller takes the column path.
+// rows a run may hold when it is made (a debug limit forces several runs out of few rows: tests)
+static uint64_t run_rows_limit(const shz_table* t) {
+  const uint64_t hard = (1ull << 32) - 4096;
+  return t->run_limit ? std::min<uint64_t>(t->run_limit, hard) : hard;
+}
+
+// The staged rows become sorted runs: one per block of block_rows[] rows if blocks are given, else one (cut into
+// several when they outgrow what a run takes).  *packed = false when the packed form does not apply (ids + offsets wider
+// than 32 bits, or the active segment holds rows): nothing was done, the caller takes the column path.
 static int32_t seal_staged(shz_table* t, const uint64_t* block_rows, uint32_t n_blocks, bool* packed) {
   shz_ctx* ctx = t->ctx;
   *packed = false;
@@ -1788,22 +1853,32 @@ static int32_t seal_staged(shz_table* t, const uint64_t* block_rows, uint32_t n_
   SHZ_TRY(drop_staged_duplicates_of_frozen(t, mm[2], mm[0]));
   t->max_sid = std::max(t->max_sid, mm[0]);
   t->max_off = std::max(t->max_off, mm[1]);
-  if (n_blocks <= 1) {
-    if (t->runs.size() + 1 > KW_MAXK) SHZ_TRY(collapse_runs(t));
-    SHZ_TRY(seal_rows(t, t->skey, t->ssid, t->soff, t->ns, mm[2], mm[0]));
-  } else {
+  std::vector<uint64_t> blocks;
+  if (n_blocks > 1) {
     uint64_t o = 0;
     for (uint32_t b = 0; b < n_blocks; ++b) {
       const uint64_t n = std::min<uint64_t>(block_rows[b], t->ns - std::min(o, t->ns));   // (the anti-join may have shortened the rows)
-      if (n) {
-        uint32_t bm[3];
-        SHZ_TRY(staged_minmax(t, o, n, bm));
-        if (t->runs.size() + 1 > KW_MAXK) SHZ_TRY(collapse_runs(t));
-        SHZ_TRY(seal_rows(t, t->skey + o, t->ssid + o, t->soff + o, n, bm[2], bm[0]));
-      }
+      blocks.push_back(n);
       o += n;
     }
     if (o < t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)o, (unsigned long long)t->ns);
+  } else {
+    blocks.push_back(t->ns);
+  }
+  const uint64_t lim = run_rows_limit(t);
+  uint64_t o = 0;
+  for (uint64_t bn : blocks) {
+    for (uint64_t done = 0; done < bn;) {
+      const uint64_t n = std::min(bn - done, lim);
+      uint32_t bm[3] = {mm[0], mm[1], mm[2]};
+      if (blocks.size() > 1 || n < t->ns) SHZ_TRY(staged_minmax(t, o, n, bm));
+      // a merge takes KW_MAXK runs: beyond that the smallest local ones are merged first (never runs that travelled with
+      // runs that did not -- the exchange ships whole local runs)
+      if (!t->hold_runs && t->runs.size() + 1 > KW_MAXK) SHZ_TRY(collapse_runs(t, KW_MAXK - 1));
+      SHZ_TRY(seal_rows(t, t->skey + o, t->ssid + o, t->soff + o, n, bm[2], bm[0]));
+      o += n;
+      done += n;
+    }
   }
   t->ns = 0;
   *packed = true;
@@ -1818,134 +1893,235 @@ extern "C" int32_t shz_table_seal_run(shz_table* t) {
   if (t->ns == 0) return SHZ_OK;
   bool packed = false;
   SHZ_TRY(seal_staged(t, nullptr, 0, &packed));
-  if (!packed) return shz_table_finalize(t);   // rows in the active segment, or ids too wide: the column path, rows visible at once
+  if (!packed) {
+    // rows in the active segment, or ids too wide to pack.  A table that holds its runs for a gathered build must not
+    // put rows where the exchange cannot find them: the rows stay staged and the caller hears about it.
+    if (t->hold_runs)
+      SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "seal_run on a table reserved with SHZ_RESERVE_GATHER: %s; the rows stay staged (shz_table_allgather "
+                                       "takes staged rows through the column path as long as no run has been sealed)",
+               t->n ? "the table already holds rows" : "song id + offset need more than 32 bits");
+    const uint64_t before = total_rows(t);
+    const int32_t rc = shz_table_finalize(t);   // the column path, rows visible at once
+    t->rows_cut += total_rows(t) - before;
+    return rc;
+  }
+  if (t->hold_runs) return SHZ_OK;   // runs wait in the arena: one merge at finalize / allgather cuts segments by key range
   while (runs_rows(t) >= std::min<uint64_t>(t->seg_limit, (1ull << 32) - 4096)) {
     const uint64_t before = runs_rows(t);
     SHZ_TRY(flush_runs(t, false));
+    t->rows_cut += before - runs_rows(t);
     if (runs_rows(t) >= before) break;
   }
   return SHZ_OK;
 }
 
-// rows gathered from every rank (or the blocks of finalize_runs) -> table.  With `c`, the sealed local rows travel as
-// ONE run per rank; all ranks pack in the layout the global maxima give.
-static int32_t build_from_runs(shz_table* t, shz_comm* c, const uint64_t* run_rows_in, uint32_t n_runs_in, uint64_t* bytes_recv) {
+// ---------------------------------------------------------------------------------------- gathered build
+// One table on every GPU from every rank's tracks (BASELINE configs[2], [4]).  The reference's only
+// parallelism already pipelines -- the parent inserts a song while the pool fingerprints the next
+// (__init__.py:341, 357-386, imap_unordered) -- and so does this: a rank's sealed runs travel on the communicator's
+// exchange stream while its own stream fingerprints the next batch.
+//
+// An exchange ROUND (collective; gx_round):
+//   1. every rank all-gathers one fixed block: its largest song id / offset so far, flags, and the row counts and
+//      song-id ranges of up to GX_MAXR runs it has sealed and not yet sent (a blocking exchange of 320 bytes a rank on
+//      the exchange stream: being in order, it also waits for the transfers of the round before);
+//   2. all ranks derive the same verdicts from the same blocks: the packing layout (run_layout, pure in the global
+//      maxima; runs packed narrower are repacked in place), whether anybody needs the column path, whether anybody has
+//      more to send;
+//   3. every rank places its peers' runs behind each other at the tail of its arena and queues the transfers
+//      (shz_comm_allgather_lists_on: piece i of every rank's list in one RCCL group, each pair of GPUs on its own xGMI
+//      link); its own runs stay where they were sealed.  The call returns with the transfers in flight.
+// shz_table_exchange_run = seal + one round.  shz_table_allgather = seal + rounds until every rank is finishing and has
+// nothing left to send, then ONE k-way merge over all runs (more than KW_MAXK: the smallest are merged first).  Ranks
+// may call exchange_run different numbers of times: a rank that is already finishing keeps taking part in rounds.
+// Every run is < 2^32 rows; a rank may hold any number of them (configs[4] at N = 2: 5.7e9 rows a rank).
+#define GX_MAXR 16
+#define GX_HDR 8
+#define GX_BLOCK (GX_HDR + 2 * GX_MAXR)   // u64 words a rank contributes to a round
+enum { GXF_GENERAL = 1, GXF_MORE = 2, GXF_FINISHING = 4, GXF_CUT = 8, GXF_HOLDS_RUNS = 16, GXF_STAGED = 32, GXF_BROKEN = 64 };
+
+struct gx_verdict {
+  bool any_general = false, any_cut = false, any_runs = false, any_more = false, all_finishing = true, any_broken = false;
+  uint64_t rows_sent = 0;   // rows that travelled in this round (all ranks')
+};
+
+// pending: this rank has staged rows it will seal after this round (largest song id / offset among them: st_sid, st_off)
+static int32_t gx_round(shz_table* t, shz_comm* c, bool finishing, bool local_general, bool local_failed, bool pending, uint32_t st_sid,
+                        uint32_t st_off, gx_verdict* v) {
   shz_ctx* ctx = t->ctx;
   int rank = 0, nranks = 1;
-  if (c) shz_comm_info(c, &rank, &nranks);
+  shz_comm_info(c, &rank, &nranks);
+  hipStream_t xs;
+  SHZ_TRY(shz_comm_exchange_stream(c, &xs));
+  // 1) this rank's block
+  std::vector<size_t> mine;   // indices of the runs this round ships
+  size_t unsent = 0;
+  bool holds = false;
+  for (size_t i = 0; i < t->runs.size(); ++i) {
+    holds |= t->runs[i].n != 0;
+    if (t->runs[i].where != RUN_LOCAL) continue;
+    ++unsent;
+    if (mine.size() < GX_MAXR) mine.push_back(i);
+  }
+  uint64_t blk[GX_BLOCK];
+  memset(blk, 0, sizeof(blk));
+  blk[0] = unsent;
+  blk[1] = std::max(t->max_sid, st_sid);
+  blk[2] = std::max(t->max_off, st_off);
+  blk[3] = total_rows(t);
+  blk[4] = (local_general ? GXF_GENERAL : 0) | (unsent > mine.size() || pending ? GXF_MORE : 0) | (finishing ? GXF_FINISHING : 0) |
+           (t->rows_cut ? GXF_CUT : 0) | (holds ? GXF_HOLDS_RUNS : 0) | (t->ns ? GXF_STAGED : 0) | (t->broken || local_failed ? GXF_BROKEN : 0);
+  blk[5] = mine.size();
+  for (size_t j = 0; j < mine.size(); ++j) {
+    const shz_run& r = t->runs[mine[j]];
+    blk[GX_HDR + 2 * j] = r.n;
+    blk[GX_HDR + 2 * j + 1] = (uint64_t)r.sid_lo | ((uint64_t)r.sid_hi << 32);
+  }
+  std::vector<uint64_t> all((size_t)GX_BLOCK * nranks);
+  const double w0 = now_s();
+  SHZ_TRY(shz_comm_allgather_host(c, blk, all.data(), sizeof(blk)));
+  t->gx_wait_s += now_s() - w0;
+  ++t->gx_rounds;
+  // 2) verdicts every rank derives alike
+  *v = gx_verdict();
+  uint64_t gmax_sid = 0, gmax_off = 0;
+  for (int r = 0; r < nranks; ++r) {
+    const uint64_t* b = &all[(size_t)GX_BLOCK * r];
+    gmax_sid = std::max(gmax_sid, b[1]);
+    gmax_off = std::max(gmax_off, b[2]);
+    v->any_general |= (b[4] & GXF_GENERAL) != 0;
+    v->any_cut |= (b[4] & GXF_CUT) != 0;
+    v->any_runs |= (b[4] & GXF_HOLDS_RUNS) != 0;
+    v->any_more |= (b[4] & GXF_MORE) != 0;
+    v->any_broken |= (b[4] & GXF_BROKEN) != 0;
+    v->all_finishing &= (b[4] & GXF_FINISHING) != 0;
+    if (b[5] > GX_MAXR) SHZ_FAIL(ctx, SHZ_E_STATE, "exchange round: rank %d announces %llu runs", r, (unsigned long long)b[5]);
+    for (uint64_t j = 0; j < b[5]; ++j) v->rows_sent += b[GX_HDR + 2 * j];
+  }
+  if (bits_for(gmax_sid) + bits_for(gmax_off) > 32) v->any_general = true;
+  if (v->any_general || v->any_cut || v->any_broken) return SHZ_OK;   // nothing travels: the caller decides (alike on every rank)
+  // 3) one layout: every run this rank holds is (re)packed in it before anything leaves
+  bool ok = false;
+  SHZ_TRY(run_layout(t, (uint32_t)gmax_sid, (uint32_t)gmax_off, &ok));
+  if (!ok) SHZ_FAIL(ctx, SHZ_E_STATE, "exchange round: the agreed layout does not fit (song id %llu, offset %llu)", (unsigned long long)gmax_sid, (unsigned long long)gmax_off);
+  t->max_sid = std::max<uint32_t>(t->max_sid, (uint32_t)gmax_sid);
+  t->max_off = std::max<uint32_t>(t->max_off, (uint32_t)gmax_off);
+  if (v->rows_sent == 0) return SHZ_OK;
+  // 4) places for the peers' runs, then the transfers
+  std::vector<shz_xfer> send;
+  std::vector<std::vector<shz_xfer>> recv(nranks);
+  std::vector<shz_run> arrivals;
+  uint64_t at = (runs_end(t) + 31) & ~31ull, recv_rows = 0;
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) continue;
+    const uint64_t* b = &all[(size_t)GX_BLOCK * r];
+    for (uint64_t j = 0; j < b[5]; ++j) {
+      const uint64_t n = b[GX_HDR + 2 * j];
+      if (n >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_STATE, "exchange round: rank %d announces a run of %llu rows", r, (unsigned long long)n);
+      shz_run nr{at, n, (uint32_t)b[GX_HDR + 2 * j + 1], (uint32_t)(b[GX_HDR + 2 * j + 1] >> 32)};
+      nr.where = RUN_RECV;
+      arrivals.push_back(nr);
+      at = (at + n + 31) & ~31ull;
+      recv_rows += n;
+    }
+  }
+  SHZ_TRY(rbuf_reserve(t, at));   // (a growing arena waits for the transfers in flight; a reserved one never grows)
+  size_t ai = 0;
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) continue;
+    const uint64_t* b = &all[(size_t)GX_BLOCK * r];
+    for (uint64_t j = 0; j < b[5]; ++j, ++ai) recv[r].push_back(shz_xfer{t->rbuf + arrivals[ai].off, arrivals[ai].n * 8});
+  }
+  for (size_t i : mine) send.push_back(shz_xfer{t->rbuf + t->runs[i].off, t->runs[i].n * 8});
+  // the exchange stream takes over once the seal (and a repack) on the context's stream is done
+  if (!t->gx_ev) SHZ_HIP(ctx, hipEventCreateWithFlags(&t->gx_ev, hipEventDisableTiming));
+  SHZ_HIP(ctx, hipEventRecord(t->gx_ev, ctx->stream));
+  SHZ_HIP(ctx, hipStreamWaitEvent(xs, t->gx_ev, 0));
+  t->gx_stream = xs;
+  const double x0 = now_s();
+  SHZ_TRY(shz_comm_allgather_lists_on(c, xs, send, recv));
+  t->gx_xfer_s += now_s() - x0;
+  for (size_t i : mine) t->runs[i].where = RUN_SENT;
+  for (const shz_run& r : arrivals)
+    if (r.n) t->runs.push_back(r);
+  t->gx_recv_bytes += recv_rows * 8;
+  return SHZ_OK;
+}
+
+// what a round's verdict means for a caller that wanted runs to travel
+static int32_t gx_refuse(shz_table* t, const gx_verdict& v, const char* who) {
+  shz_ctx* ctx = t->ctx;
+  if (v.any_broken) SHZ_FAIL(ctx, SHZ_E_STATE, "%s: a rank failed to seal its rows, or its table lost rows in a failed finalize", who);
+  if (v.any_cut)
+    SHZ_FAIL(ctx, SHZ_E_STATE, "%s: a rank's seal_run moved rows into table segments before the exchange (they cannot travel any more): "
+                               "reserve the tables of a gathered build with SHZ_RESERVE_GATHER, which keeps sealed runs in the arena", who);
+  if (v.any_general && v.any_runs)
+    SHZ_FAIL(ctx, SHZ_E_STATE, "%s: a rank needs the column path (its table holds rows, or song id + offset need more than 32 bits) "
+                               "while sealed runs wait on some rank: the tables would differ between ranks", who);
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_exchange_run(shz_table* t, shz_comm* c) {
+  if (!t || !c) return SHZ_E_INVALID;
+  shz_ctx* ctx = t->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (shz_comm_ctx(c) != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "exchange_run: table and communicator belong to different contexts");
+  t->hold_runs = true;
+  // the round is entered whatever happened locally: a rank that fails alone would leave its peers waiting in theirs
+  int32_t rc_local = SHZ_OK;
+  bool local_general = t->n || !t->done.empty();
+  if (!local_general && t->ns) {
+    bool packed = false;
+    rc_local = seal_staged(t, nullptr, 0, &packed);
+    if (rc_local == SHZ_OK && !packed) local_general = true;
+  }
+  const std::string err_local = ctx->err;
+  gx_verdict v;
+  SHZ_TRY(gx_round(t, c, false, local_general, rc_local != SHZ_OK, false, 0, 0, &v));
+  if (rc_local != SHZ_OK) { ctx->err = err_local; return rc_local; }
+  SHZ_TRY(gx_refuse(t, v, "shz_table_exchange_run"));
+  if (v.any_general)
+    SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "shz_table_exchange_run: a rank's rows cannot travel as packed runs (its table holds rows, or song id + "
+                                     "offset need more than 32 bits); stage everything and call shz_table_allgather");
+  return SHZ_OK;
+}
+
+// the build without a communicator: the staged rows (n_runs_in blocks, what that many ranks would have staged) and the
+// sealed runs -> table, one k-way merge
+static int32_t build_from_runs(shz_table* t, const uint64_t* run_rows_in, uint32_t n_runs_in) {
+  shz_ctx* ctx = t->ctx;
   t->bs_sort = t->bs_exchange = t->bs_merge = t->bs_segments = 0.0;
-  if (bytes_recv) *bytes_recv = 0;
-  static const bool force_cols = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "columns"); }();
-  // this rank's rows: staged + already sealed.  Maxima first -- every rank must pack alike.
   uint32_t mm[3] = {0u, 0u, 0xFFFFFFFFu};
   if (t->ns) SHZ_TRY(staged_minmax(t, 0, t->ns, mm));
   for (const shz_run& r : t->runs)
-    if (r.n) { mm[0] = std::max(mm[0], r.sid_hi); mm[2] = std::min(mm[2], r.sid_lo); }
-  const uint64_t local_off_max = std::max<uint64_t>(mm[1], t->runs.empty() ? 0 : t->max_off);   // (max_off covers every sealed run)
-  const uint64_t local_rows = t->ns + runs_rows(t);
-  // the general (column) path if ANY rank needs it: a table that already holds rows, ids + offsets too wide to pack
-  const bool local_general = t->n || !t->done.empty() || force_cols || bits_for(mm[0]) + bits_for(local_off_max) > 32;
-  std::vector<uint64_t> info(5 * (size_t)nranks, 0);
-  uint64_t* mine = &info[5 * (size_t)rank];
-  mine[0] = local_rows; mine[1] = mm[0]; mine[2] = local_off_max; mine[3] = mm[2]; mine[4] = local_general ? 1 : 0;
-  if (c && nranks > 1) {
-    void* d;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 40ull * (nranks + 1), &d));
-    uint64_t* d_info = (uint64_t*)d;
-    SHZ_HIP(ctx, shz_memcpy(ctx, d_info, mine, 40, hipMemcpyHostToDevice));
-    SHZ_TRY(shz_comm_allgather_bytes(c, d_info, d_info + 5, 40));
-    SHZ_HIP(ctx, shz_memcpy(ctx, info.data(), d_info + 5, 40ull * nranks, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  uint64_t total = 0, gmax_sid = 0, gmax_off = 0;
-  bool any_general = false;
-  std::vector<uint64_t> cnt(nranks);
-  for (int r = 0; r < nranks; ++r) {
-    cnt[r] = info[5 * (size_t)r];
-    total += cnt[r];
-    gmax_sid = std::max(gmax_sid, info[5 * (size_t)r + 1]);
-    gmax_off = std::max(gmax_off, info[5 * (size_t)r + 2]);
-    any_general |= info[5 * (size_t)r + 4] != 0;
-  }
-  if (bits_for(gmax_sid) + bits_for(gmax_off) > 32) any_general = true;
-  if (any_general) return SHZ_I_GENERAL_PATH;
-  if (total == 0) return shz_table_finalize(t);
-  // 1) local rows -> sorted run(s) in the agreed layout
+    if (r.n) mm[0] = std::max(mm[0], r.sid_hi);
+  const uint64_t off_max = std::max<uint64_t>(mm[1], t->runs.empty() ? 0 : t->max_off);   // (max_off covers every sealed run)
+  if (t->n || !t->done.empty() || bits_for(mm[0]) + bits_for(off_max) > 32) return SHZ_I_GENERAL_PATH;
+  if (t->ns + runs_rows(t) == 0) return shz_table_finalize(t);
   double t0 = now_s();
-  bool ok = false;
-  SHZ_TRY(run_layout(t, (uint32_t)gmax_sid, (uint32_t)gmax_off, &ok));
-  t->max_sid = std::max<uint32_t>(t->max_sid, (uint32_t)gmax_sid);
-  t->max_off = std::max<uint32_t>(t->max_off, (uint32_t)gmax_off);
   if (t->ns) {
     bool packed = false;
-    if (!c && n_runs_in) {
+    if (n_runs_in) {
       uint64_t sum = 0;
       for (uint32_t i = 0; i < n_runs_in; ++i) sum += run_rows_in[i];
       if (sum != t->ns) SHZ_FAIL(ctx, SHZ_E_INVALID, "runs cover %llu rows, %llu are staged", (unsigned long long)sum, (unsigned long long)t->ns);
     }
-    SHZ_TRY(seal_staged(t, c ? nullptr : run_rows_in, c ? 0 : n_runs_in, &packed));
+    SHZ_TRY(seal_staged(t, run_rows_in, n_runs_in, &packed));
     if (!packed) SHZ_FAIL(ctx, SHZ_E_STATE, "build_from_runs: rows could not be packed");
   }
-  if (!c || nranks == 1) {
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    t->bs_sort = now_s() - t0;
-    t0 = now_s();
-    const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE], s0 = t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET];
-    SHZ_TRY(flush_runs(t, true));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    t->bs_merge = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE] - m0;
-    t->bs_segments = std::max(now_s() - t0 - t->bs_merge, t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET] - s0);
-    return SHZ_OK;
-  }
-  SHZ_TRY(collapse_runs(t));   // one run per rank travels
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->bs_sort = now_s() - t0;
-  // duplicates inside the local run are gone; what the other ranks hold is what they counted BEFORE their own dedup, so
-  // the run lengths are exchanged again (8 bytes a rank)
-  const uint64_t my_rows = runs_rows(t);
-  {
-    void* d;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC2, 8ull * (nranks + 1), &d));
-    SHZ_HIP(ctx, shz_memcpy(ctx, d, &my_rows, 8, hipMemcpyHostToDevice));
-    SHZ_TRY(shz_comm_allgather_bytes(c, d, (uint64_t*)d + 1, 8));
-    SHZ_HIP(ctx, shz_memcpy(ctx, cnt.data(), (uint64_t*)d + 1, 8ull * nranks, hipMemcpyDeviceToHost));
-    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  // 2) exchange: every rank's run lands behind this rank's own in the run arena, 256-byte aligned
   t0 = now_s();
-  std::vector<uint64_t> displ(nranks), bcnt(nranks), bdis(nranks);
-  const uint64_t src_off = t->runs.empty() ? 0 : t->runs[0].off;
-  uint64_t at = (src_off + my_rows + 31) & ~31ull;
-  total = 0;
-  for (int r = 0; r < nranks; ++r) {
-    displ[r] = at;
-    at = (at + cnt[r] + 31) & ~31ull;
-    total += cnt[r];
-    if (cnt[r] >= (1ull << 32) - 4096) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "rank %d holds %llu rows (a run is limited to < 2^32)", r, (unsigned long long)cnt[r]);
-  }
-  SHZ_TRY(rbuf_reserve(t, at));
-  const uint64_t g0 = displ[0];
-  for (int r = 0; r < nranks; ++r) { bcnt[r] = cnt[r] * 8; bdis[r] = (displ[r] - g0) * 8; }
-  SHZ_TRY(shz_comm_allgatherv_bytes(c, t->rbuf + src_off, t->rbuf + g0, bcnt.data(), bdis.data()));
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (bytes_recv) *bytes_recv = (total - my_rows) * 8;
-  t->bs_exchange = now_s() - t0;
-  // 3) the gathered runs replace the local one; rank r's rows carry the song ids rank r reported
-  t->runs.clear();
-  for (int r = 0; r < nranks; ++r)
-    if (cnt[r]) t->runs.push_back(shz_run{displ[r], cnt[r], (uint32_t)info[5 * (size_t)r + 3], (uint32_t)info[5 * (size_t)r + 1]});
-  while (t->runs.size() > KW_MAXK) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "more than %d ranks", KW_MAXK);
-  t0 = now_s();
-  const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE];
+  const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE], s0 = t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET];
   SHZ_TRY(flush_runs(t, true));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   t->bs_merge = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE] - m0;
-  t->bs_segments = now_s() - t0 - t->bs_merge;
+  t->bs_segments = std::max(now_s() - t0 - t->bs_merge, t->ph[PH_COL_ALLOC] + t->ph[PH_BUCKET] - s0);
   return SHZ_OK;
 }
 
 // the exchange of unsorted columns followed by one sort of everything: tables that already hold rows, or ids / offsets
-// too wide for the packed form
+// too wide for the packed form.  Only STAGED rows travel (the caller has made sure no rank holds sealed runs).
 static int32_t allgather_columns(shz_table* t, shz_comm* c, uint64_t* bytes_recv) {
   shz_ctx* ctx = t->ctx;
   int rank, nranks;
@@ -1978,14 +2154,22 @@ static int32_t allgather_columns(shz_table* t, shz_comm* c, uint64_t* bytes_recv
   t->bs_sort = t->bs_merge = 0.0;
   t->bs_exchange = now_s() - t0;
   // 3) the gathered columns become the staged rows; finalize sorts + dedups them with the existing table
-  void* olds[] = {t->skey, t->ssid, t->soff};
-  for (void* p : olds)
-    if (p) SHZ_HIP(ctx, hipFree(p));
+  if (t->stage_reserved) {
+    uint32_t* st[3] = {t->skey, t->ssid, t->soff};
+    for (int i = 0; i < 3; ++i) shz_block_free(ctx, st[i], t->st_bytes[i]);
+  } else {
+    void* olds[] = {t->skey, t->ssid, t->soff};
+    for (void* p : olds)
+      if (p) SHZ_HIP(ctx, hipFree(p));
+  }
   t->skey = gc.take(0); t->ssid = gc.take(1); t->soff = gc.take(2);
   t->ns = t->scap = total;
   t->stage_reserved = false;
   const double t1 = now_s();
+  const bool hold = t->hold_runs;
+  t->hold_runs = false;   // (finalize of a table that holds rows: the column path proper)
   const int32_t rc = shz_table_finalize(t);
+  t->hold_runs = hold;
   t->bs_segments = now_s() - t1;
   return rc;
 }
@@ -1994,9 +2178,63 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
   if (!t || !c) return SHZ_E_INVALID;
   shz_ctx* ctx = t->ctx;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
-  const int32_t rc = build_from_runs(t, c, nullptr, 0, bytes_recv);
-  return rc == SHZ_I_GENERAL_PATH ? allgather_columns(t, c, bytes_recv) : rc;
+  if (shz_comm_ctx(c) != ctx) SHZ_FAIL(ctx, SHZ_E_INVALID, "allgather: table and communicator belong to different contexts");
+  if (bytes_recv) *bytes_recv = 0;
+  static const bool force_cols = [] { const char* e = getenv("SHZ_ALLGATHER"); return e && !strcmp(e, "columns"); }();
+  t->bs_sort = t->bs_exchange = t->bs_merge = t->bs_segments = 0.0;
+  // 1) A first round with nothing sealed here yet: does ANY rank need the column path (its table holds rows, ids too
+  //    wide, SHZ_ALLGATHER=columns)?  Then the staged rows must stay staged -- on every rank -- to travel as columns.  The
+  //    block carries the staged rows' maxima, so the layout agreed in this round already covers them.
+  double t0 = now_s();
+  uint32_t mm[3] = {0u, 0u, 0xFFFFFFFFu};
+  int32_t rc_local = SHZ_OK;
+  if (t->ns) rc_local = staged_minmax(t, 0, t->ns, mm);
+  const uint32_t lmax_sid = std::max(t->max_sid, mm[0]), lmax_off = std::max(t->max_off, mm[1]);
+  const bool local_general = t->n || !t->done.empty() || force_cols || (t->ns && bits_for(lmax_sid) + bits_for(lmax_off) > 32);
+  std::string err_local = ctx->err;
+  gx_verdict v;
+  SHZ_TRY(gx_round(t, c, true, local_general, rc_local != SHZ_OK, t->ns != 0, mm[0], mm[1], &v));
+  // 2) the packed path: staged rows become runs (a local failure is carried into the next round: a rank that left
+  //    alone would leave its peers waiting), then rounds until every rank is here and has sent everything
+  if (!(v.any_general || v.any_cut || v.any_broken)) {
+    if (rc_local == SHZ_OK && t->ns) {
+      bool packed = false;
+      rc_local = seal_staged(t, nullptr, 0, &packed);
+      if (rc_local == SHZ_OK && !packed) { rc_local = SHZ_E_STATE; ctx->err = "allgather: staged rows could not be packed in the agreed layout"; }
+      err_local = ctx->err;
+    }
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->bs_sort = now_s() - t0;
+    while (!(v.all_finishing && !v.any_more)) {   // (what the last round queued is the last of it)
+      SHZ_TRY(gx_round(t, c, true, false, rc_local != SHZ_OK, false, 0, 0, &v));
+      if (v.any_general || v.any_cut || v.any_broken) break;
+    }
+  }
+  if (rc_local != SHZ_OK) { ctx->err = err_local; return rc_local; }
+  SHZ_TRY(gx_refuse(t, v, "shz_table_allgather"));
+  if (v.any_general) {
+    t->rows_cut = 0;
+    return allgather_columns(t, c, bytes_recv);   // (no rank holds a run: only staged rows exist, and they all travel)
+  }
+  // 3) every run is here (or on its way: flush_runs waits): one merge
+  if (t->gx_stream) {
+    const double w0 = now_s();
+    SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));
+    t->gx_wait_s += now_s() - w0;
+  }
+  if (bytes_recv) *bytes_recv = t->gx_recv_bytes;
+  t->bs_exchange = t->gx_xfer_s + t->gx_wait_s;   // host seconds inside exchange rounds (waiting for peers included), not link time
+  t->gx_recv_bytes = 0;
+  t->gx_wait_s = t->gx_xfer_s = 0.0;
+  t->rows_cut = 0;
+  if (runs_rows(t) == 0) { t->runs.clear(); return shz_table_finalize(t); }
+  t0 = now_s();
+  const double m0 = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE];
+  SHZ_TRY(flush_runs(t, true));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  t->bs_merge = t->ph[PH_KW_PLAN] + t->ph[PH_KW_MERGE] - m0;
+  t->bs_segments = now_s() - t0 - t->bs_merge;
+  return SHZ_OK;
 }
 
 extern "C" int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_rows, uint32_t n_runs) {
@@ -2004,8 +2242,25 @@ extern "C" int32_t shz_table_finalize_runs(shz_table* t, const uint64_t* run_row
   shz_ctx* ctx = t->ctx;
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
   if (t->broken) SHZ_FAIL(ctx, SHZ_E_STATE, "table lost rows in a failed finalize");
-  const int32_t rc = build_from_runs(t, nullptr, run_rows, n_runs, nullptr);
+  const int32_t rc = build_from_runs(t, run_rows, n_runs);
   return rc == SHZ_I_GENERAL_PATH ? shz_table_finalize(t) : rc;   // not an empty table / ids too wide
+}
+
+/* rows a sealed run may hold (0: the hard limit, 2^32 - 4096): small values force several runs out of few rows (tests) */
+extern "C" int32_t shz_table_set_run_rows(shz_table* t, uint64_t rows) {
+  if (!t) return SHZ_E_INVALID;
+  if (rows && rows < 16) SHZ_FAIL(t->ctx, SHZ_E_INVALID, "run rows must be 0 or >= 16");
+  t->run_limit = rows;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_table_exchange_stats(shz_table* t, uint64_t* rounds, uint64_t* bytes_recv, double* wait_s, uint32_t* runs_held) {
+  if (!t) return SHZ_E_INVALID;
+  if (rounds) *rounds = t->gx_rounds;
+  if (bytes_recv) *bytes_recv = t->gx_recv_bytes;
+  if (wait_s) *wait_s = t->gx_wait_s;
+  if (runs_held) *runs_held = (uint32_t)t->runs.size();
+  return SHZ_OK;
 }
 
 extern "C" int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, double* merge_s, double* segments_s) {

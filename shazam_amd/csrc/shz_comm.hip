@@ -1,6 +1,8 @@
 // RCCL communicator for the multi-GPU database build.  librccl.so is opened
 // lazily with dlopen so single-GPU users never load it; one rank per GPU, the ncclUniqueId
-// travels between ranks through the host (torch.distributed store / any side channel).
+// travels between ranks through the host (any side channel the caller has: a file, a socket, MPI, a key-value store).
+// A communicator owns a second stream: the runs of the gathered build travel on it while the context's own stream
+// fingerprints the next batch.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -73,6 +75,7 @@ struct local_group {
   uint64_t generation = 0;
   std::vector<const void*> send;                 // what every rank published for the exchange in flight
   std::vector<std::vector<uint64_t>> displ;      // alltoallv: the publisher's send displacements
+  std::vector<std::vector<const void*>> sendv;   // all-gather of lists: the publisher's buffers
   bool broken = false;                           // a rank gave up waiting: everybody fails from then on
 };
 static std::mutex g_groups_mu;
@@ -100,20 +103,26 @@ struct shz_comm {
   int rank, nranks;
   local_group* lg = nullptr;   // non-null: the in-process transport
   uint64_t lg_id = 0;
+  hipStream_t xs = nullptr;    // the exchange stream (created on first use)
+  void* d_info = nullptr;      // small device block for the rounds' info exchange (not a context workspace slot: the
+  void* h_info = nullptr;      //   context's stream may be busy with other work), and its pinned host mirror
 };
+#define SHZ_COMM_INFO_BYTES (64u << 10)
 
 // one exchange of the in-process transport: every rank publishes its send buffer (data complete: own stream drained), all
 // meet, `copy(p, send pointer of rank p, displacements of rank p)` pulls what this rank wants from rank p, all meet again
 // (nobody touches its send buffer before every peer has read it)
 template <class F>
-static int32_t local_exchange(shz_comm* c, const void* d_send, const uint64_t* my_displ, F&& copy) {
+static int32_t local_exchange(shz_comm* c, hipStream_t s, const void* d_send, const uint64_t* my_displ, F&& copy,
+                              const std::vector<const void*>* my_list = nullptr) {
   shz_ctx* ctx = c->ctx;
   local_group* g = c->lg;
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(s));
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->send[c->rank] = d_send;
     if (my_displ) g->displ[c->rank].assign(my_displ, my_displ + c->nranks);
+    if (my_list) g->sendv[c->rank] = *my_list;
   }
   if (!local_barrier(g)) SHZ_FAIL(ctx, SHZ_E_RCCL, "in-process exchange: a rank did not arrive");
   for (int p = 0; p < c->nranks; ++p) {
@@ -124,14 +133,14 @@ static int32_t local_exchange(shz_comm* c, const void* d_send, const uint64_t* m
       sp = g->send[p];
       if (my_displ) dp = g->displ[p];
     }
-    const hipError_t e = copy(p, sp, dp);
+    const hipError_t e = copy(p, sp, dp);   // (a list exchange reads g->sendv[p] itself: nobody writes it between the barriers)
     if (e != hipSuccess) {
       { std::lock_guard<std::mutex> lk(g->mu); g->broken = true; }
       g->cv.notify_all();
       SHZ_FAIL(ctx, SHZ_E_HIP, "in-process exchange: copy from rank %d failed: %s", p, hipGetErrorString(e));
     }
   }
-  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SHZ_HIP(ctx, hipStreamSynchronize(s));
   if (!local_barrier(g)) SHZ_FAIL(ctx, SHZ_E_RCCL, "in-process exchange: a rank did not arrive");
   return SHZ_OK;
 }
@@ -147,6 +156,7 @@ extern "C" int32_t shz_comm_create_local(shz_ctx* ctx, uint64_t group_id, int32_
       g->nranks = nranks;
       g->send.assign(nranks, nullptr);
       g->displ.resize(nranks);
+      g->sendv.resize(nranks);
       g_groups[group_id] = g;
     } else {
       g = it->second;
@@ -195,6 +205,9 @@ extern "C" int32_t shz_comm_destroy(shz_comm* c) {
   if (!c) return SHZ_E_INVALID;
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->xs) { (void)hipStreamSynchronize(c->xs); (void)hipStreamDestroy(c->xs); }
+  if (c->d_info) (void)hipFree(c->d_info);
+  if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->lg) {
     std::lock_guard<std::mutex> lk(g_groups_mu);
     if (--c->lg->attached == 0) {
@@ -216,14 +229,107 @@ int32_t shz_comm_info(shz_comm* c, int* rank, int* nranks) {
   return SHZ_OK;
 }
 
+// the exchange stream and the info blocks, made on first use
+int32_t shz_comm_exchange_stream(shz_comm* c, hipStream_t* out) {
+  shz_ctx* ctx = c->ctx;
+  if (!c->xs) {
+    SHZ_HIP(ctx, hipSetDevice(ctx->device));
+    SHZ_HIP(ctx, hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    SHZ_HIP(ctx, hipMalloc(&c->d_info, 2 * SHZ_COMM_INFO_BYTES));
+    SHZ_HIP(ctx, hipHostMalloc(&c->h_info, 2 * SHZ_COMM_INFO_BYTES, hipHostMallocDefault));
+  }
+  *out = c->xs;
+  return SHZ_OK;
+}
+
 // all-gather of equal-sized byte blocks: recv must hold nranks*bytes
-int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes) {
+int32_t shz_comm_allgather_bytes_on(shz_comm* c, hipStream_t s, const void* d_send, void* d_recv, uint64_t bytes) {
   shz_ctx* ctx = c->ctx;
   if (c->lg)
-    return local_exchange(c, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
-      return bytes ? hipMemcpyAsync((char*)d_recv + (uint64_t)p * bytes, sp, bytes, hipMemcpyDefault, ctx->stream) : hipSuccess;
+    return local_exchange(c, s, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
+      return bytes ? hipMemcpyAsync((char*)d_recv + (uint64_t)p * bytes, sp, bytes, hipMemcpyDefault, s) : hipSuccess;
     });
-  SHZ_NCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, NCCL_U8, c->comm, ctx->stream));
+  SHZ_NCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, NCCL_U8, c->comm, s));
+  return SHZ_OK;
+}
+int32_t shz_comm_allgather_bytes(shz_comm* c, const void* d_send, void* d_recv, uint64_t bytes) {
+  return shz_comm_allgather_bytes_on(c, c->ctx->stream, d_send, d_recv, bytes);
+}
+
+// All-gather of a HOST block of `bytes` (<= SHZ_COMM_INFO_BYTES / nranks) per rank on the exchange stream: h_all receives
+// nranks blocks in rank order.  Blocks until the blocks are there -- and, the stream being in order, until every
+// transfer queued on it before has finished.
+int32_t shz_comm_allgather_host(shz_comm* c, const void* h_mine, void* h_all, uint64_t bytes) {
+  shz_ctx* ctx = c->ctx;
+  hipStream_t s;
+  SHZ_TRY(shz_comm_exchange_stream(c, &s));
+  if (bytes * (uint64_t)c->nranks > SHZ_COMM_INFO_BYTES) SHZ_FAIL(ctx, SHZ_E_INVALID, "info block of %llu bytes x %d ranks", (unsigned long long)bytes, c->nranks);
+  memcpy(c->h_info, h_mine, bytes);
+  char* d_recv = (char*)c->d_info + SHZ_COMM_INFO_BYTES;
+  char* h_recv = (char*)c->h_info + SHZ_COMM_INFO_BYTES;
+  SHZ_HIP(ctx, hipMemcpyAsync(c->d_info, c->h_info, bytes, hipMemcpyHostToDevice, s));
+  SHZ_TRY(shz_comm_allgather_bytes_on(c, s, c->d_info, d_recv, bytes));
+  SHZ_HIP(ctx, hipMemcpyAsync(h_recv, d_recv, bytes * c->nranks, hipMemcpyDeviceToHost, s));
+  SHZ_HIP(ctx, hipStreamSynchronize(s));
+  memcpy(h_all, h_recv, bytes * c->nranks);
+  return SHZ_OK;
+}
+
+// All-gather of LISTS of buffers on stream s: every rank's buffers send[0..] go to every peer; recv[p] says where the
+// buffers of peer p land here (same number and sizes as p's own send list -- every rank knows every list from the
+// info exchange before).  A rank's own buffers stay where they are (recv[rank] is ignored).  Returns when the
+// transfers are QUEUED (RCCL) -- the caller orders other streams against s with events; the in-process transport
+// returns when they are done.  RCCL: the lists are cut into pieces of <= 1 GB; piece i of every rank travels in one
+// group -- a send to and a receive from each peer, every pair of GPUs on its own xGMI link.
+int32_t shz_comm_allgather_lists_on(shz_comm* c, hipStream_t s, const std::vector<shz_xfer>& send,
+                                    const std::vector<std::vector<shz_xfer>>& recv) {
+  shz_ctx* ctx = c->ctx;
+  if ((int)recv.size() != c->nranks) SHZ_FAIL(ctx, SHZ_E_INVALID, "allgather_lists: %zu receive lists for %d ranks", recv.size(), c->nranks);
+  if (c->lg) {
+    std::vector<const void*> mine;
+    for (const shz_xfer& x : send) mine.push_back(x.p);
+    local_group* g = c->lg;
+    return local_exchange(c, s, nullptr, nullptr, [&](int p, const void*, const std::vector<uint64_t>&) -> hipError_t {
+      if (p == c->rank) return hipSuccess;
+      std::vector<const void*> theirs;
+      { std::lock_guard<std::mutex> lk(g->mu); theirs = g->sendv[p]; }
+      if (theirs.size() != recv[p].size()) return hipErrorInvalidValue;
+      for (size_t i = 0; i < theirs.size(); ++i)
+        if (recv[p][i].bytes) {
+          const hipError_t e = hipMemcpyAsync(recv[p][i].p, theirs[i], recv[p][i].bytes, hipMemcpyDefault, s);
+          if (e != hipSuccess) return e;
+        }
+      return hipSuccess;
+    }, &mine);
+  }
+  if (c->nranks == 1) return SHZ_OK;
+  rccl_api* r = rccl();
+  if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd) SHZ_FAIL(ctx, SHZ_E_RCCL, "librccl.so lacks ncclSend/ncclRecv");
+  const uint64_t PIECE = 1ull << 30;
+  auto pieces = [&](const std::vector<shz_xfer>& l) {
+    std::vector<shz_xfer> v;
+    for (const shz_xfer& x : l)
+      for (uint64_t o = 0; o < x.bytes; o += PIECE) v.push_back(shz_xfer{(char*)x.p + o, std::min(PIECE, x.bytes - o)});
+    return v;
+  };
+  const std::vector<shz_xfer> mine = pieces(send);
+  std::vector<std::vector<shz_xfer>> theirs(c->nranks);
+  size_t rounds = mine.size();
+  for (int p = 0; p < c->nranks; ++p)
+    if (p != c->rank) { theirs[p] = pieces(recv[p]); rounds = std::max(rounds, theirs[p].size()); }
+  for (size_t i = 0; i < rounds; ++i) {
+    ncclResult_t bad = (ncclResult_t)0;
+    const char* what = "";
+    auto step = [&](ncclResult_t rc, const char* w) { if (rc != 0 && bad == 0) { bad = rc; what = w; } };
+    step(r->GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < c->nranks && bad == 0; ++p) {
+      if (p == c->rank) continue;
+      if (i < mine.size()) step(r->Send(mine[i].p, mine[i].bytes, NCCL_U8, p, c->comm, s), "ncclSend");
+      if (i < theirs[p].size()) step(r->Recv(theirs[p][i].p, theirs[p][i].bytes, NCCL_U8, p, c->comm, s), "ncclRecv");
+    }
+    step(r->GroupEnd(), "ncclGroupEnd");   // the group is closed whatever happened inside it
+    if (bad != 0) SHZ_FAIL(ctx, SHZ_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(bad) : "rccl error");
+  }
   return SHZ_OK;
 }
 
@@ -237,7 +343,7 @@ int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv,
                                   const uint64_t* displ) {
   shz_ctx* ctx = c->ctx;
   if (c->lg)
-    return local_exchange(c, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
+    return local_exchange(c, ctx->stream, d_send, nullptr, [&](int p, const void* sp, const std::vector<uint64_t>&) {
       return counts[p] ? hipMemcpyAsync((char*)d_recv + displ[p], sp, counts[p], hipMemcpyDefault, ctx->stream) : hipSuccess;
     });
   rccl_api* r = rccl();
@@ -281,7 +387,7 @@ int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t
                                  void* d_recv, const uint64_t* rcount, const uint64_t* rdispl) {
   shz_ctx* ctx = c->ctx;
   if (c->lg)
-    return local_exchange(c, d_send, sdispl, [&](int p, const void* sp, const std::vector<uint64_t>& dp) {
+    return local_exchange(c, ctx->stream, d_send, sdispl, [&](int p, const void* sp, const std::vector<uint64_t>& dp) {
       return rcount[p] ? hipMemcpyAsync((char*)d_recv + rdispl[p], (const char*)sp + dp[c->rank], rcount[p], hipMemcpyDefault, ctx->stream)
                        : hipSuccess;
     });

@@ -195,3 +195,11 @@ int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t
                                  void* d_recv, const uint64_t* rcount, const uint64_t* rdispl);
 int32_t shz_comm_allgatherv_bytes(shz_comm* c, const void* d_send, void* d_recv, const uint64_t* counts,
                                   const uint64_t* displ);
+// the gathered build's transport: a second stream owned by the communicator, a blocking all-gather of small host
+// blocks on it, and the all-gather of lists of device buffers (see shz_comm.hip)
+struct shz_xfer { void* p; uint64_t bytes; };
+int32_t shz_comm_exchange_stream(shz_comm* c, hipStream_t* out);
+int32_t shz_comm_allgather_bytes_on(shz_comm* c, hipStream_t s, const void* d_send, void* d_recv, uint64_t bytes);
+int32_t shz_comm_allgather_host(shz_comm* c, const void* h_mine, void* h_all, uint64_t bytes);
+int32_t shz_comm_allgather_lists_on(shz_comm* c, hipStream_t s, const std::vector<shz_xfer>& send,
+                                    const std::vector<std::vector<shz_xfer>>& recv);

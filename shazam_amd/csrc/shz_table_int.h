@@ -26,9 +26,11 @@ struct shz_seg_dev {  // what the match kernels see
 #define SHZ_TABLE_PHASES 24
 
 // a sorted run of packed rows (key << (sb + ob) | sid << ob | off) waiting in the run arena for the k-way merge
+enum { RUN_LOCAL = 0 /* made here, no peer has it yet */, RUN_SENT = 1 /* made here, every peer has it */, RUN_RECV = 2 /* a peer's */ };
 struct shz_run {
   uint64_t off, n;             // position / rows in shz_table::rbuf
   uint32_t sid_lo, sid_hi;     // song ids of the run: runs with disjoint ranges cannot hold the same row
+  uint8_t where = RUN_LOCAL;   // gathered build: has the run travelled?
 };
 struct shz_reserve_job;        // background allocation of the arenas (shz_table_reserve)
 
@@ -60,6 +62,16 @@ struct shz_table {
   double votes_per_hash = 0.0;                          // of the last match against this table (0: none yet): whether a single query's votes are worth queueing ahead of their count
   bool stage_reserved = false;                          // the staging columns were sized by shz_table_reserve: kept
   shz_reserve_job* job = nullptr;
+  // ---- gathered build (shz_table_exchange_run / shz_table_allgather)
+  bool hold_runs = false;                               // sealed runs wait in the arena until finalize / allgather, seal_run never cuts a segment (until the final merge)
+  bool hold_reserved = false;                           // ... asked for by shz_table_reserve(SHZ_RESERVE_GATHER): every bulk build of this table holds its runs
+  uint64_t run_limit = 0;                               // rows a sealed run may hold (0: 2^32 - 4096); small values force many runs (tests)
+  uint64_t rows_cut = 0;                                // rows seal_run moved into segments since the last allgather / clear: they cannot travel any more
+  uint64_t gx_recv_bytes = 0, gx_rounds = 0;            // payload received / exchange rounds since the last allgather
+  double gx_wait_s = 0.0, gx_xfer_s = 0.0;              // host seconds waiting for peers / transfers inside exchange rounds; queueing (in-process transport: making) the transfers
+  hipEvent_t gx_ev = nullptr;                           // "the runs this round ships are complete" (context's stream -> exchange stream)
+  hipStream_t gx_stream = nullptr;                      // a transfer into / out of the arena may be in flight on this stream
+  uint32_t* d_kw_err = nullptr;                         // error word of the k-way merge's tile kernels
 };
 
 // phases of the single-GPU build, in the order shz_table_phase_stats reports them

@@ -1,7 +1,7 @@
 """Sharded database build: tracks are partitioned over the ranks (one process per
 GPU), every rank fingerprints its own block on its GPU and stages rows (key32, song_id, offset),
-then ONE exchange step -- an RCCL all-gather of the staged rows over xGMI -- leaves the same
-node-global table on every GPU.
+seals them into sorted runs that travel to every peer over RCCL/xGMI while the next batch is fingerprinted;
+one k-way merge of all runs leaves the same node-global table on every GPU.
 
 The reference's only parallelism is the file-level multiprocessing.Pool of
 fingerprint_directory (__init__.py:335-357); song ids there are MySQL auto-increment values in
@@ -85,18 +85,32 @@ class ShardedBuilder:
 
     ``pcm_source(lo, hi)`` returns either a list of int16 arrays (host PCM) or a tuple
     ``(DevBuf, n_samples)`` of device-resident equal-length clips for tracks [lo, hi).
+
+    The build is pipelined like the reference's (the parent inserts a song while the pool fingerprints the next,
+    __init__.py:341, 357-386): whenever ``seal_rows`` rows are staged they are sealed into a sorted run, and with a
+    communicator the run starts travelling to the peers (``Table.exchange_run``) while the next chunk is fingerprinted.
+    Staging never holds more than ``seal_rows`` + one chunk of rows, a run is always < 2^32 rows, and the table holds its
+    runs (``reserve(gather=True)``) so that ONE merge at the end cuts the segments by key range.  ``rows_hint``: expected
+    rows of the WHOLE corpus (all ranks) -- the arenas are then allocated once, beside the first chunks.
     """
 
-    def __init__(self, db, rank: int = 0, world: int = 1, comm=None, chunk_tracks: int = 256):
+    def __init__(self, db, rank: int = 0, world: int = 1, comm=None, chunk_tracks: int = 256, seal_rows: int = 1_000_000_000):
         self.db, self.rank, self.world, self.comm, self.chunk = db, rank, world, comm, int(chunk_tracks)
+        self.seal_rows = int(seal_rows)
         if world > 1 and comm is None:
-            raise ValueError("world > 1 needs an RCCL communicator (shazam_amd._ffi.Comm)")
+            raise ValueError("world > 1 needs a communicator (shazam_amd._ffi.Comm)")
 
-    def build(self, n_tracks: int, pcm_source, Fs: int = 44100):
+    def build(self, n_tracks: int, pcm_source, Fs: int = 44100, rows_hint: int = 0):
         import shazam_amd as S
         lo, hi = shard_tracks(n_tracks, self.rank, self.world)
-        ctx = self.db.ctx
-        n_hashes = 0
+        ctx, tbl = self.db.ctx, self.db.table
+        if tbl.rows() == (0, 0):   # a fresh table: the bulk build (a table that holds rows takes the column path at the end)
+            batch = min(self.seal_rows, -(-int(rows_hint) // self.world)) if rows_hint else 0
+            tbl.reserve(int(rows_hint), batch, gather=True)
+            bulk = True
+        else:
+            bulk = False
+        n_hashes = staged = runs = 0
         for c0 in range(lo, hi, self.chunk):
             c1 = min(c0 + self.chunk, hi)
             src = pcm_source(c0, c1)
@@ -109,13 +123,20 @@ class ShardedBuilder:
                 cnt = len(k)
             self.db.insert_clips(k, t1, ho, sid0=song_id_of_track(c0))
             n_hashes += cnt
+            staged += cnt
+            if bulk and staged >= self.seal_rows:
+                if self.comm is not None:
+                    tbl.exchange_run(self.comm)
+                else:
+                    tbl.seal_run()
+                staged, runs = 0, runs + 1
         recv = 0
         if self.comm is not None:
-            recv = self.db.table.allgather(self.comm)
+            recv = tbl.allgather(self.comm)
             self.db._dirty = False
         else:
             self.db.finalize()
-        return {"tracks": hi - lo, "hashes": n_hashes, "bytes_received": recv, "rows": self.db.table.rows()[0]}
+        return {"tracks": hi - lo, "hashes": n_hashes, "bytes_received": recv, "rows": tbl.rows()[0], "runs_sealed_on_the_way": runs}
 
 
 # ---------------------------------------------------------------------------------------------

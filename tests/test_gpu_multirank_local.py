@@ -9,6 +9,12 @@ rendezvous + device copies instead of ncclSend/ncclRecv).  What RCCL itself move
   shz_table_allgather: all ranks end with the same table, equal to the one-rank build row for row, and answer queries alike;
   also: a rank without rows, a rank that sealed runs on the way, ids too wide to pack (every rank takes the column path),
   a rank whose table already holds rows (ditto);
+* the gathered build at the shapes BASELINE's configs put it in: a rank that seals several times a
+  segment's worth, lists of runs per rank (several rounds, more runs than one merge takes), runs that travel while the next
+  batch is staged (exchange_run, ranks calling it different numbers of times), a layout that widens mid-build; and the two
+  situations in which the tables WOULD differ -- wide ids on one rank with sealed runs on another, a table that was not
+  reserved for gathering and has cut segments -- fail on every rank alike;
+* ShardedBuilder (ingest.py) over thread ranks == its one-rank build;
 * key-sharded table: all-to-all build + per-shard votes + all-gather of the votes == the unsharded table."""
 import threading
 
@@ -112,6 +118,172 @@ def test_allgather_build_equals_one_rank_build(world, case):
             assert np.array_equal(res[name], outs[0][1][name]), (case, r, name)
     if case == "plain":
         assert all(o[2] > 0 for o in outs) and all(o[3]["merge_s"] > 0 for o in outs)
+
+
+def _build_ranks(world, gid, n_tracks, blocks, per_rank):
+    """per_rank(r, tbl, comm, lo, hi, insert) stages / seals rank r's tracks; returns (rows, match result, recv, stats) per rank."""
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    from shazam_amd.ingest import shard_tracks
+    qk = np.concatenate([b[0][:40] for b in blocks[::17]])
+    qo = np.concatenate([b[2][:40] for b in blocks[::17]])
+    qoff = np.arange(0, len(qk) + 1, 40).astype(np.uint64)
+
+    def rank_fn(r):
+        ctx = _ffi.Context(0)
+        comm = _ffi.Comm.local(ctx, gid, r, world)
+        tbl = S.Table(ctx)
+        try:
+            lo, hi = shard_tracks(n_tracks, r, world)
+            per_rank(r, tbl, comm, lo, hi)
+            recv = tbl.allgather(comm)
+            k, s, o = tbl.export()
+            rows = np.stack([k, s, o], 1).astype(np.uint64)
+            return rows, tbl.match(qk, qo, qoff, 3), recv, tbl.build_stats(), tbl.segments(), tbl.exchange_stats()
+        finally:
+            tbl.close()
+            comm.close()
+            ctx.close()
+
+    return _run_ranks(world, rank_fn)
+
+
+def _check_equal_tables(outs, want):
+    for r, out in enumerate(outs):
+        rows = out[0]
+        assert len(rows) == len(want) and np.array_equal(rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))], want), r
+        for name in outs[0][1]:
+            assert np.array_equal(out[1][name], outs[0][1][name]), (r, name)
+
+
+@pytest.mark.parametrize("world, case", [(3, "sealed_3x_segment"), (3, "many_runs"), (2, "two_rounds_of_runs"), (4, "pipelined"),
+                                         (3, "pipelined_widening"), (2, "pipelined_one_rank_never")])
+def test_gathered_build_with_lists_of_runs(world, case):
+    n_tracks, per_track = 240, 900
+    rng = np.random.default_rng(world * 7 + len(case))
+    blocks = []
+    for tr in range(n_tracks):
+        # "widening": the last tracks of the LAST rank are long -- the layout every rank packs in grows mid-build
+        noff = 5000 if case == "pipelined_widening" and tr >= n_tracks - 20 else 600
+        blocks.append(_rows(rng, per_track, tr + 1, tr + 2, noff=noff))
+    want = np.unique(np.concatenate([np.stack(b, 1) for b in blocks]).astype(np.uint64), axis=0)
+    gid = 5000 + world * 16 + sum(map(ord, case))
+
+    def per_rank(r, tbl, comm, lo, hi):
+        tbl.set_segment_rows(20000)
+        tbl.reserve(0, 0, gather=True)          # hold the runs: nothing is cut before the exchange
+        if case == "many_runs":
+            tbl.set_run_rows(5000)              # 72,000 rows a rank -> 15 runs a rank, 45 in all: more than one merge takes
+        if case == "two_rounds_of_runs":
+            tbl.set_run_rows(4000)              # 108,000 rows a rank -> 27 runs: two exchange rounds of <= 16
+        for i, tr in enumerate(range(lo, hi)):
+            tbl.insert(*blocks[tr])
+            if case == "sealed_3x_segment" and r == 1 and i % 20 == 19:
+                tbl.seal_run()                  # rank 1 seals 72,000 rows: 3.6 segments' worth
+            if case.startswith("pipelined"):
+                every = (7, 11, 13, 19)[r % 4]  # ranks call exchange_run different numbers of times
+                if case == "pipelined_one_rank_never" and r == 1:
+                    continue
+                if i % every == every - 1:
+                    tbl.exchange_run(comm)
+
+    outs = _build_ranks(world, gid, n_tracks, blocks, per_rank)
+    _check_equal_tables(outs, want)
+    for out in outs:
+        assert out[4] >= 2                      # several segments (cut by key range)
+        assert out[2] > 0
+    if case == "two_rounds_of_runs":
+        assert all(o[5]["rounds"] >= 2 for o in outs)
+    if case.startswith("pipelined"):
+        assert all(o[5]["rounds"] >= 3 for o in outs)
+
+
+@pytest.mark.parametrize("case", ["wide_ids_and_sealed_runs", "unreserved_table_cut_segments", "hold_mode_wide_seal"])
+def test_gathered_build_fails_on_every_rank_instead_of_diverging(case):
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    from shazam_amd.ingest import shard_tracks
+    world, n_tracks = 3, 90
+    rng = np.random.default_rng(len(case))
+    wide = lambda tr: case != "unreserved_table_cut_segments" and tr < 30   # noqa: E731  rank 0's tracks
+    blocks = [_rows(rng, 900, tr + 1 + ((1 << 24) if wide(tr) else 0), tr + 2 + ((1 << 24) if wide(tr) else 0), noff=4000 if wide(tr) else 600)
+              for tr in range(n_tracks)]
+    gid = 9000 + sum(map(ord, case))
+
+    def rank_fn(r):
+        ctx = _ffi.Context(0)
+        comm = _ffi.Comm.local(ctx, gid, r, world)
+        tbl = S.Table(ctx)
+        tbl.set_segment_rows(10000)
+        out = {"seal_error": None, "gather_error": None}
+        try:
+            if case != "unreserved_table_cut_segments":
+                tbl.reserve(0, 0, gather=True)
+            lo, hi = shard_tracks(n_tracks, r, world)
+            for i, tr in enumerate(range(lo, hi)):
+                tbl.insert(*blocks[tr])
+                seals = (case == "wide_ids_and_sealed_runs" and r == 1) or (case == "unreserved_table_cut_segments" and r == 1) or \
+                        (case == "hold_mode_wide_seal" and r == 0)
+                if seals and i % 10 == 9:
+                    try:
+                        tbl.seal_run()
+                    except _ffi.ShzError as e:
+                        out["seal_error"] = e.code
+            try:
+                tbl.allgather(comm)
+            except _ffi.ShzError as e:
+                out["gather_error"] = e.code
+            out["rows"] = tbl.rows()
+            return out
+        finally:
+            tbl.close()
+            comm.close()
+            ctx.close()
+
+    outs = _run_ranks(world, rank_fn)
+    if case == "hold_mode_wide_seal":
+        # seal_run refuses (the rows stay staged) and says so; with no run sealed anywhere the column path still builds the table
+        assert outs[0]["seal_error"] == _ffi.E_UNSUPPORTED
+        assert all(o["gather_error"] is None for o in outs)
+        want = len(np.unique(np.concatenate([np.stack(b, 1) for b in blocks]).astype(np.uint64), axis=0))
+        assert all(o["rows"] == (want, 0) for o in outs)
+    else:
+        assert all(o["gather_error"] == _ffi.E_STATE for o in outs), outs
+
+
+def test_sharded_builder_over_thread_ranks_equals_one_rank():
+    """ingest.ShardedBuilder as a user drives it: device-resident synthetic tracks, runs sealed and sent on the way."""
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    from shazam_amd.db import HipFingerprintDB
+    from shazam_amd.ingest import ShardedBuilder
+    n_tracks, n_samples, world = 36, 2048 * 60, 3
+
+    def run(world_, r, comm_of):
+        ctx = _ffi.Context(0)
+        comm = comm_of(ctx)
+        db = HipFingerprintDB(ctx=ctx)
+        db.table.set_segment_rows(9000)
+
+        def source(lo, hi):
+            return ctx.synth_pcm(4242, lo, hi - lo, n_samples, 3000, 1500), n_samples
+
+        b = ShardedBuilder(db, r, world_, comm, chunk_tracks=4, seal_rows=3000)
+        info = b.build(n_tracks, source, rows_hint=0)
+        k, s, o = db.table.export()
+        segs = db.table.segments()
+        db.close()
+        if comm is not None:
+            comm.close()
+        ctx.close()
+        return np.stack([k, s, o], 1).astype(np.uint64), info, segs
+
+    ref_rows, ref_info, ref_segs = run(1, 0, lambda ctx: None)
+    assert ref_info["runs_sealed_on_the_way"] >= 2 and ref_segs >= 2
+    outs = _run_ranks(world, lambda r: run(world, r, lambda ctx: _ffi.Comm.local(ctx, 777001, r, world)))
+    for rows, info, segs in outs:
+        assert np.array_equal(rows, ref_rows)           # same rows in the same order: segments cut by key range concatenate to the sorted table
+        assert info["runs_sealed_on_the_way"] >= 1 and info["bytes_received"] > 0
 
 
 def test_key_sharded_table_over_thread_ranks():
