@@ -289,68 +289,82 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
 
 
 def db_build_scaling(a, ctx, dist, comm, rank, world):
-    """Fixed corpus of a.scaling_songs x 30 s tracks split over the ranks; seconds from the first fingerprint call to the
-    node-global table standing on every GPU (max over ranks), PCM synthesis (the stand-in for audio decoding) excluded."""
+    """STRONG scaling of the database build on BASELINE configs[2] as written: ONE fixed corpus of a.scaling_songs x
+    a.scaling_seconds tracks (100,000 x 3 min), the same at every N, split over the ranks in contiguous blocks and built
+    by the product's own driver (shazam_amd.ingest.ShardedBuilder): fingerprint a chunk, stage its rows, every ~1e9 rows
+    (or the rank's share) seal a sorted run and start it travelling to the peers while the next chunk is fingerprinted,
+    one k-way merge of all runs at the end.  `seconds` = max over ranks of (first chunk .. table standing on the GPU)
+    minus the PCM synthesis kernels' own time (events; the stand-in for audio decoding, which is not the product).  The
+    table's arenas are reserved before the clock starts and the time that took is reported beside it."""
     import bench_db
-    from shazam_amd import _ffi, Table
-    from shazam_amd.ingest import shard_tracks
-    songs, seconds, chunk = a.scaling_songs, 30.0, 1000
-    n_samples = int(round(seconds * FS))
-    frames = int(_ffi.lib().shz_frame_count(n_samples))
+    from shazam_amd import _ffi
+    from shazam_amd.db import HipFingerprintDB
+    from shazam_amd.ingest import ShardedBuilder, shard_tracks
+    songs, seconds = a.scaling_songs, a.scaling_seconds
+    note = None
+
+    def plan(sec):
+        n_samples = int(round(sec * FS))
+        frames = int(_ffi.lib().shz_frame_count(n_samples))
+        rows_total = int(songs * frames * bench_db.ROWS_PER_FRAME_HINT)
+        seal = min(1_000_000_000, -(-rows_total // world))
+        # columns + arena of all runs + staging + one sort scratch + the extraction workspace and PCM of a chunk
+        need = rows_total * 12 * 1.03 + (rows_total * 1.02 + seal * 1.2) * 8 + seal * 1.1 * 20 + 24e9
+        return n_samples, frames, rows_total, seal, need
+
+    n_samples, frames, rows_total, seal, need = plan(seconds)
+    free_b, total_b = ctx.mem_info()
+    if need > 0.93 * total_b:
+        note = f"{songs} x {seconds:.0f} s needs ~{need / 1e9:.0f} GB of HBM, {total_b / 1e9:.0f} GB here: 30 s tracks instead"
+        seconds = 30.0
+        n_samples, frames, rows_total, seal, need = plan(seconds)
+    chunk = max(16, min(1000, int(700_000 // frames)))   # ~700k frames a fingerprint call (the headline step holds 644k)
     lo, hi = shard_tracks(songs, rank, world)
-    rows_total = int(songs * frames * bench_db.ROWS_PER_FRAME_HINT)
-    rows_local = int((hi - lo) * frames * bench_db.ROWS_PER_FRAME_HINT)
-    tbl = Table(ctx)
-    # setup, outside the timed region: the table's arenas exist before the clock starts (device memory that went through
-    # hipFree earlier in the process comes back scrubbed by the driver at ~40 GB/s, and that stalls kernel launches)
-    tbl.reserve(rows_total, rows_local, gather=world > 1, wait=True)
-    cap = chunk * frames * 24 + 1024
-    kbuf, tbuf, pcm = ctx.alloc(cap * 4), ctx.alloc(cap * 4), ctx.alloc(chunk * n_samples * 2)
+    db = HipFingerprintDB(ctx=ctx)
+    pcm = ctx.alloc(chunk * n_samples * 2)
+    synth_ms = [0.0]
+
+    def source(c0, c1):   # PCM synthesis: its kernel time (events on the context's stream) is taken out of `seconds`
+        ctx.timer_start(7)
+        ctx.synth_pcm(bench_db.SEED_TRACKS, c0, c1 - c0, n_samples, 4000, 1500, out=pcm)
+        synth_ms[0] += ctx.timer_stop(7)
+        return pcm, n_samples
+
+    # setup, outside the clock (reported): the arenas exist before the first chunk (device memory that went through hipFree
+    # earlier in the process comes back scrubbed by the driver at ~40 GB/s, and that stalls kernel launches)
+    t0 = time.perf_counter()
+    db.table.reserve(rows_total, seal, gather=True, wait=True)
+    t_reserve = time.perf_counter() - t0
+    builder = ShardedBuilder(db, rank, world, comm, chunk_tracks=chunk, seal_rows=seal)
     if dist:
         dist.barrier()
     ctx.sync()
-    t_synth = t_fp = t_ins = 0.0
     t_all0 = time.perf_counter()
-    for c0 in range(lo, hi, chunk):
-        n = min(chunk, hi - c0)
-        t0 = time.perf_counter()
-        ctx.synth_pcm(bench_db.SEED_TRACKS, c0, n, n_samples, 4000, 1500, out=pcm)
-        ctx.sync()
-        t1 = time.perf_counter()
-        _, _, ho, _ = ctx.fingerprint_batch(pcm, np.arange(n + 1, dtype=np.uint64) * n_samples, fs=FS, pcm_device=True,
-                                            out_key=kbuf, out_t1=tbuf, cap=cap)
-        ctx.sync()
-        t2 = time.perf_counter()
-        tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
-        t3 = time.perf_counter()
-        t_synth += t1 - t0
-        t_fp += t2 - t1
-        t_ins += t3 - t2
-    t0 = time.perf_counter()
-    recv = tbl.allgather(comm) if comm else 0
-    if not comm:
-        tbl.finalize()
-    ctx.sync()
-    t_table = time.perf_counter() - t0
+    info = builder.build(songs, source, Fs=FS, rows_hint=rows_total)
     if dist:
         dist.barrier()
     t_wall = time.perf_counter() - t_all0
-    vals = [t_wall - t_synth, t_fp, t_ins + t_table, t_synth]
+    t_synth = synth_ms[0] / 1e3
+    vals = [t_wall - t_synth, info["fingerprint_s"], info["insert_s"], info["seal_exchange_s"], info["final_s"], t_synth, t_reserve]
     if dist:
         import torch
         tt = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in tt]
-    rows, _ = tbl.rows()
+    rows, _ = db.table.rows()
     o = {"songs": songs, "clip_seconds": seconds, "n_gpus": world, "scaling": "strong", "seconds": vals[0],
          "songs_per_s": songs / vals[0], "audio_s_per_s": songs * seconds / vals[0], "fingerprint_s": vals[1],
-         "table_s": vals[2], "synth_s_excluded": vals[3], "rows": int(rows), "segments": int(tbl.segments()),
-         "allgather_bytes_received": int(recv), "build_stats_s": tbl.build_stats(),
-         "phases_s": {k: round(v, 4) for k, v in tbl.phase_stats().items() if v > 5e-4},
-         "note": "seconds = max over ranks of (first fingerprint call .. table standing) minus PCM synthesis; the same corpus at every N"}
-    tbl.close()
-    for b_ in (kbuf, tbuf, pcm):
-        b_.free()
+         "insert_s": vals[2], "seal_and_send_s": vals[3], "final_rounds_and_merge_s": vals[4], "synth_s_excluded": vals[5],
+         "reserve_s_outside_clock": vals[6], "rows": int(rows), "segments": int(db.table.segments()),
+         "runs_sent_on_the_way_rank0": info["runs_sealed_on_the_way"], "chunk_tracks": chunk, "seal_rows": seal,
+         "allgather_bytes_received": int(info["bytes_received"]), "build_stats_s": db.table.build_stats(),
+         "exchange": db.table.exchange_stats(),
+         "phases_s": {k: round(v, 4) for k, v in db.table.phase_stats().items() if v > 5e-4},
+         "config": "BASELINE configs[2]" + ("" if note is None else " at 30 s tracks: " + note),
+         "note": "seconds = max over ranks of (first chunk .. table standing) minus the synthesis kernels' event time; the same "
+                 "corpus at every N; sealed runs travel on the communicator's stream beside the next chunk's fingerprinting"}
+    db.close()
+    pcm.free()
     return o
 
 
@@ -452,6 +466,7 @@ def main():
                     "smaller sub-batches, e.g. so that one sub-batch's staged spectrogram stays in the 256 MB Infinity Cache (experiment)")
     ap.add_argument("--scaling-songs", type=int, default=100000, help="fixed corpus of the db_build_scaling extra: the same "
                     "at every --gpus N (0 = skip)")
+    ap.add_argument("--scaling-seconds", type=float, default=180.0, help="track length of that corpus (BASELINE configs[2]: 3 min)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:

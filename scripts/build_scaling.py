@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""The db_build_scaling leg of bench.py on its own (BASELINE configs[2]: 100,000 x 3 min tracks into one table).
+
+    python scripts/build_scaling.py --songs 100000 --seconds 180                 # one GPU, what bench.py --gpus 1 reports
+    python scripts/build_scaling.py --songs 4000 --seconds 180 --local-ranks 4   # the N > 1 code path with thread ranks
+                                                                                 # on ONE GPU (logic rehearsal, not a scaling number:
+                                                                                 # the ranks share the GPU and every rank holds the whole table)
+Prints one JSON line per run.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+import types
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--songs", type=int, default=100000)
+    ap.add_argument("--seconds", type=float, default=180.0)
+    ap.add_argument("--local-ranks", type=int, default=1)
+    a = ap.parse_args()
+    import bench
+    from shazam_amd import _ffi
+    args = types.SimpleNamespace(scaling_songs=a.songs, scaling_seconds=a.seconds)
+    if a.local_ranks <= 1:
+        ctx = _ffi.Context(0)
+        t0 = time.perf_counter()
+        o = bench.db_build_scaling(args, ctx, None, None, 0, 1)
+        o["wall_incl_setup_s"] = time.perf_counter() - t0
+        print(json.dumps(o))
+        return
+    world = a.local_ranks
+    bar = threading.Barrier(world)
+    outs, errs = [None] * world, [None] * world
+
+    class Dist:   # what db_build_scaling needs of torch.distributed, between threads
+        class ReduceOp:
+            MAX = "max"
+        vals = [None] * world
+
+        def __init__(self, r):
+            self.r = r
+
+        def barrier(self):
+            bar.wait()
+
+        def all_reduce(self, t, op=None):
+            Dist.vals[self.r] = t.clone()
+            bar.wait()
+            import torch
+            m = torch.stack(Dist.vals).max(0).values
+            bar.wait()
+            t.copy_(m)
+
+    def go(r):
+        try:
+            ctx = _ffi.Context(0)
+            comm = _ffi.Comm.local(ctx, 31337, r, world)
+            outs[r] = bench.db_build_scaling(args, ctx, Dist(r), comm, r, world)
+            comm.close()
+            ctx.close()
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+            bar.abort()
+
+    ths = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    o = outs[0]
+    o["transport"] = f"{world} thread ranks on one GPU (in-process transport)"
+    o["rows_all_ranks"] = [x["rows"] for x in outs]
+    print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

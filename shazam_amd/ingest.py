@@ -100,43 +100,81 @@ class ShardedBuilder:
         if world > 1 and comm is None:
             raise ValueError("world > 1 needs a communicator (shazam_amd._ffi.Comm)")
 
-    def build(self, n_tracks: int, pcm_source, Fs: int = 44100, rows_hint: int = 0):
+    def build(self, n_tracks: int, pcm_source, Fs: int = 44100, rows_hint: int = 0, reserve_wait: bool = False):
+        import time
+
         import shazam_amd as S
+        from . import _ffi
         lo, hi = shard_tracks(n_tracks, self.rank, self.world)
         ctx, tbl = self.db.ctx, self.db.table
-        if tbl.rows() == (0, 0):   # a fresh table: the bulk build (a table that holds rows takes the column path at the end)
+        bulk = tbl.rows() == (0, 0)   # a fresh table: the bulk build (a table that holds rows takes the column path at the end)
+        if bulk:
             batch = min(self.seal_rows, -(-int(rows_hint) // self.world)) if rows_hint else 0
-            tbl.reserve(int(rows_hint), batch, gather=True)
-            bulk = True
-        else:
-            bulk = False
+            tbl.reserve(int(rows_hint), batch, gather=True, wait=reserve_wait)
         n_hashes = staged = runs = 0
+        t_src = t_fp = t_ins = t_seal = 0.0
+        kbuf = tbuf = None
+        cap = 0
+        t_begin = time.perf_counter()
         for c0 in range(lo, hi, self.chunk):
             c1 = min(c0 + self.chunk, hi)
+            t0 = time.perf_counter()
             src = pcm_source(c0, c1)
-            if isinstance(src, tuple):
+            t1_ = time.perf_counter()
+            if isinstance(src, tuple):   # device PCM: the fingerprints stay on the device too
                 buf, n = src
                 off = np.arange(c1 - c0 + 1, dtype=np.uint64) * int(n)
-                k, t1, ho, cnt = ctx.fingerprint_batch(buf, off, fs=Fs, pcm_device=True)
+                need = (c1 - c0) * int(_ffi.lib().shz_frame_count(int(n))) * 24 + 1024
+                while True:
+                    if cap < need:
+                        for b_ in (kbuf, tbuf):
+                            if b_ is not None:
+                                b_.free()
+                        cap = need
+                        kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
+                    try:
+                        _, _, ho, cnt = ctx.fingerprint_batch(buf, off, fs=Fs, pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
+                        break
+                    except _ffi.ShzError as e:
+                        if e.code != _ffi.E_CAPACITY:
+                            raise
+                        need = cap * 2
+                t2 = time.perf_counter()
+                self.db.insert_clips(kbuf, tbuf, ho, sid0=song_id_of_track(c0), device=True)
             else:
                 k, t1, ho = S.fingerprint_batch(src, Fs, ctx=ctx)
                 cnt = len(k)
-            self.db.insert_clips(k, t1, ho, sid0=song_id_of_track(c0))
+                t2 = time.perf_counter()
+                self.db.insert_clips(k, t1, ho, sid0=song_id_of_track(c0))
+            t3 = time.perf_counter()
             n_hashes += cnt
             staged += cnt
             if bulk and staged >= self.seal_rows:
                 if self.comm is not None:
-                    tbl.exchange_run(self.comm)
+                    tbl.exchange_run(self.comm)   # the run travels while the next chunk is fingerprinted
                 else:
                     tbl.seal_run()
                 staged, runs = 0, runs + 1
+            t4 = time.perf_counter()
+            t_src += t1_ - t0
+            t_fp += t2 - t1_
+            t_ins += t3 - t2
+            t_seal += t4 - t3
+        t0 = time.perf_counter()
         recv = 0
         if self.comm is not None:
             recv = tbl.allgather(self.comm)
             self.db._dirty = False
         else:
             self.db.finalize()
-        return {"tracks": hi - lo, "hashes": n_hashes, "bytes_received": recv, "rows": tbl.rows()[0], "runs_sealed_on_the_way": runs}
+        ctx.sync()
+        t_end = time.perf_counter()
+        for b_ in (kbuf, tbuf):
+            if b_ is not None:
+                b_.free()
+        return {"tracks": hi - lo, "hashes": n_hashes, "bytes_received": recv, "rows": tbl.rows()[0], "runs_sealed_on_the_way": runs,
+                "seconds": t_end - t_begin, "source_s": t_src, "fingerprint_s": t_fp, "insert_s": t_ins, "seal_exchange_s": t_seal,
+                "final_s": t_end - t0}
 
 
 # ---------------------------------------------------------------------------------------------
