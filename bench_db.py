@@ -43,10 +43,13 @@ def synth_tracks(ctx, corpus, c0, nc, n_samples, tone_amp, noise_amp, out, start
 
 
 def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1500, finalize_every=0, shards=1,
-                progress=None, reserve=True, corpus="tonal"):
+                progress=None, reserve=True, corpus="tonal", hold=True):
     """Synthesise `songs` tracks on the device, fingerprint them in chunks and build one HBM table.
     Every `finalize_every` songs the staged rows are sealed into a sorted run (bounded staging and sort scratch; rows become
-    visible at the final finalize).  Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
+    visible at the final finalize).  hold: the table keeps its runs until ONE merge at the end cuts the segments by key
+    range (a query hash is then looked up in one segment) -- needs the arena to hold every row beside the columns
+    (20 B a row); when that does not fit, full segments are cut on the way as before (every segment spans every key).
+    Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
     from shazam_amd import _ffi, Table
     n_samples = int(round(seconds * FS))
     frames = int(_ffi.lib().shz_frame_count(n_samples))
@@ -55,9 +58,21 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
         tbl = ShardedTable(ctx, nshards=shards)
     else:
         tbl = Table(ctx)
+        held = False
         if reserve:   # the table's arenas in one go, allocated beside the first fingerprint batches
             per_batch = finalize_every if finalize_every else songs
-            tbl.reserve(int(songs * frames * ROWS_PER_FRAME_HINT), int(min(per_batch, songs) * frames * ROWS_PER_FRAME_HINT))
+            rows_hint, batch_hint = int(songs * frames * ROWS_PER_FRAME_HINT), int(min(per_batch, songs) * frames * ROWS_PER_FRAME_HINT)
+            if hold:
+                try:
+                    tbl.reserve(rows_hint, batch_hint, gather=True)
+                    held = True
+                except _ffi.ShzError as e:
+                    if e.code != _ffi.E_NOMEM:
+                        raise
+                    tbl.close()          # (the refused reservation left the hold flag set: start over)
+                    tbl = Table(ctx)
+            if not held:
+                tbl.reserve(rows_hint, batch_hint)
     cap = chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
     pcm = ctx.alloc(chunk * n_samples * 2)
@@ -94,6 +109,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     stats = {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
              "rows_inserted": int(n_rows_in), "rows": int(rows), "songs_per_s": songs / t_build,
              "audio_s_per_s": songs * seconds / t_build, "segments": int(tbl.segments()) if shards == 1 else None,
+             "key_range_segments": bool(shards == 1 and reserve and held),
              "phases_s": {k: round(v, 4) for k, v in tbl.phase_stats().items() if v > 5e-4} if shards == 1 else None}
     return tbl, stats, (kbuf, tbuf, cap)
 
@@ -179,13 +195,15 @@ def main():
                     "noise; music: music-like tracks under traffic-like query noise")
     ap.add_argument("--shards", type=int, default=1, help="partition the table by key into this many shards on the GPU "
                     "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
+    ap.add_argument("--no-hold", action="store_true", help="cut full segments on the way (bounded arena; every segment spans every "
+                    "key) instead of holding all runs for one merge into key-range segments")
     a = ap.parse_args()
 
     from shazam_amd import _ffi
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     n_samples = int(round(a.seconds * FS))
     tbl, build, (kbuf, tbuf, cap) = build_table(ctx, a.songs, a.seconds, a.chunk, a.tone_amp, a.noise_amp,
-                                                a.finalize_every, a.shards, corpus=a.corpus)
+                                                a.finalize_every, a.shards, corpus=a.corpus, hold=not a.no_hold)
     rows = build["rows"]
 
     qn = int(round(a.query_seconds * FS))

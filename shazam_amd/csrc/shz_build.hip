@@ -489,6 +489,7 @@ static int32_t finalize_active(shz_table* t, const uint32_t* skey, const uint32_
   SHZ_HIP(ctx, hipGetLastError());
   uint32_t last_key = 0;
   SHZ_HIP(ctx, shz_memcpy(ctx, &last_key, nk + (nu - 1), 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, &t->act_key_lo, nk, 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   pc.lap(PH_COMPACT);
   t->n = nu;
@@ -577,10 +578,12 @@ static int32_t compact_cols(shz_ctx* ctx, uint32_t* key, uint32_t* sid, uint32_t
 }
 
 // bucket index of a sorted segment whose rows changed
-static int32_t rebuild_buckets(shz_ctx* ctx, uint32_t* key, uint64_t n, uint32_t** bucket, uint64_t* nbuckets, uint64_t* bcap) {
-  if (n == 0) { *nbuckets = 0; return SHZ_OK; }
+static int32_t rebuild_buckets(shz_ctx* ctx, uint32_t* key, uint64_t n, uint32_t** bucket, uint64_t* nbuckets, uint64_t* bcap,
+                               uint32_t* key_lo) {
+  if (n == 0) { *nbuckets = 0; *key_lo = 0; return SHZ_OK; }
   uint32_t last_key = 0;
   SHZ_HIP(ctx, shz_memcpy(ctx, &last_key, key + (n - 1), 4, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, shz_memcpy(ctx, key_lo, key, 4, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t nb = (uint64_t)(last_key >> 8) + 1;
   if (nb + 1 > *bcap) {
@@ -631,7 +634,7 @@ extern "C" int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, ui
     if (kept != g.n) {
       gone += g.n - kept;
       g.n = kept;
-      SHZ_TRY(rebuild_buckets(ctx, g.key, g.n, &g.bucket, &g.nbuckets, &bcap));
+      SHZ_TRY(rebuild_buckets(ctx, g.key, g.n, &g.bucket, &g.nbuckets, &bcap, &g.key_lo));
     }
   }
   // frozen segments that became empty disappear
@@ -647,7 +650,7 @@ extern "C" int32_t shz_table_delete_songs(shz_table* t, const uint32_t* sids, ui
     if (kept != t->n) {
       gone += t->n - kept;
       t->n = kept;
-      SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap));
+      SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap, &t->act_key_lo));
     }
   }
   if (t->ns) {
@@ -680,6 +683,7 @@ extern "C" int32_t shz_table_clear(shz_table* t) {
   t->slab_used = 0;
   t->act_sid_lo = 0xFFFFFFFFu;
   t->act_sid_hi = 0;
+  t->act_key_lo = 0;
   t->n = 0;        // the active and staging columns keep their allocations for the rows to come
   t->nbuckets = 0;
   t->ns = 0;
@@ -705,7 +709,7 @@ static int32_t drop_staged_duplicates_of_frozen(shz_table* t, uint32_t sid_lo, u
   hipLaunchKernelGGL(tbl_ones_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)fl, t->ns);
   for (const shz_seg& g : t->done) {
     if (!g.n || !ranges_overlap(g.sid_lo, g.sid_hi, sid_lo, sid_hi)) continue;
-    shz_seg_dev gd{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets};
+    const shz_seg_dev gd = seg_dev_of(g);
     hipLaunchKernelGGL(tbl_exists_kernel, dim3((unsigned)((t->ns + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)t->skey, (const uint32_t*)t->ssid, (const uint32_t*)t->soff, t->ns, gd, (uint32_t*)fl);
   }
@@ -718,13 +722,14 @@ static int32_t drop_staged_duplicates_of_frozen(shz_table* t, uint32_t sid_lo, u
 
 static void freeze_active(shz_table* t) {
   if (!t->n) return;
-  t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab});
+  t->done.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab, t->act_key_lo});
   t->key = t->sid = t->off = t->bucket = nullptr;
   t->n = t->nbuckets = 0;
   t->cap = t->bcap = 0;
   t->act_slab = false;
   t->act_sid_lo = 0xFFFFFFFFu;
   t->act_sid_hi = 0;
+  t->act_key_lo = 0;
 }
 
 extern "C" int32_t shz_table_finalize(shz_table* t) {
@@ -1710,7 +1715,7 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     t->act_sid_lo = sid_lo;
     t->act_sid_hi = sid_hi;
     pc.lap(PH_KW_MERGE);
-    SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap));
+    SHZ_TRY(rebuild_buckets(ctx, t->key, t->n, &t->bucket, &t->nbuckets, &t->bcap, &t->act_key_lo));
     pc.lap(PH_BUCKET);
   }
   if (t->n && !(last_active && n_seg == n_pieces)) freeze_active(t);

@@ -334,7 +334,9 @@ __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* _
     const uint64_t b = key >> 8;
     const uint32_t* __restrict__ tkey = segs[sg].key;
     uint32_t lo = 0, rows = 0;
-    if (b < segs[sg].nbuckets && segs[sg].n) {
+    // a segment is asked only for keys inside [its first key, its last bucket]: the segments of one k-way merge hold
+    // disjoint key ranges, so one of them answers and the others cost this compare (not a bucket fetch + searches)
+    if (b < segs[sg].nbuckets && key >= segs[sg].key_lo && segs[sg].n) {
       uint32_t l = segs[sg].bucket[b], h = segs[sg].bucket[b + 1];
       const uint32_t h0 = h;
       while (l < h) {  // lower_bound(key)
@@ -1851,8 +1853,8 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
   }
   // segment descriptors for the kernels (an empty table probes one empty segment)
   std::vector<shz_seg_dev> hsegs;
-  for (const shz_seg& g : all_segs(t)) hsegs.push_back(shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.nbuckets});
-  if (hsegs.empty()) hsegs.push_back(shz_seg_dev{nullptr, nullptr, nullptr, t->bucket, 0u, 0ull});
+  for (const shz_seg& g : all_segs(t)) hsegs.push_back(seg_dev_of(g));
+  if (hsegs.empty()) hsegs.push_back(shz_seg_dev{nullptr, nullptr, nullptr, t->bucket, 0u, 0u, 0ull});
   const int nseg = (int)hsegs.size();
   m_bits mb;
   mb.sb = bits_for(t->max_sid);

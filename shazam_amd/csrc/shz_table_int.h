@@ -15,12 +15,16 @@ struct shz_seg {
   uint64_t n, nbuckets;
   uint32_t sid_lo = 0, sid_hi = 0xFFFFFFFFu;   // song ids the segment may hold (conservative, inclusive)
   bool slab = false;                           // columns carved from the table's slab: never freed on their own
+  uint32_t key_lo = 0;                         // first key of the segment (its last is (nbuckets << 8) - 1 at most): the segments
+                                               //   one k-way merge cuts hold disjoint key ranges, and a probe skips the foreign ones
 };
 struct shz_seg_dev {  // what the match kernels see
   const uint32_t *key, *sid, *off, *bucket;
   uint32_t n;
-  uint64_t nbuckets;
+  uint32_t key_lo;      // first key (keys below it have no rows here)
+  uint64_t nbuckets;    // ((last key) >> 8) + 1
 };
+static inline shz_seg_dev seg_dev_of(const shz_seg& g) { return shz_seg_dev{g.key, g.sid, g.off, g.bucket, (uint32_t)g.n, g.key_lo, g.nbuckets}; }
 #define SHZ_MAX_SEGS 32
 
 #define SHZ_TABLE_PHASES 24
@@ -51,6 +55,7 @@ struct shz_table {
   double ph[SHZ_TABLE_PHASES] = {0};   // host seconds per build phase since the last reset (shz_table_phase_stats)
   // ---- bulk build: staged rows become sorted runs, runs become segments in one k-way merge (shz_build.hip)
   uint32_t act_sid_lo = 0, act_sid_hi = 0xFFFFFFFFu;   // song ids of the active segment
+  uint32_t act_key_lo = 0;                              // its first key
   bool act_slab = false;                                // the active columns are carved from the slab
   char* slab = nullptr;                                 // ONE allocation the segments' columns are carved from
   uint64_t slab_bytes = 0, slab_used = 0;
@@ -100,7 +105,7 @@ struct ph_clock {
 
 static inline std::vector<shz_seg> all_segs(const shz_table* t) {
   std::vector<shz_seg> v = t->done;
-  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab});
+  if (t->n) v.push_back(shz_seg{t->key, t->sid, t->off, t->bucket, t->n, t->nbuckets, t->act_sid_lo, t->act_sid_hi, t->act_slab, t->act_key_lo});
   return v;
 }
 static inline uint64_t total_rows(const shz_table* t) {

@@ -80,6 +80,117 @@ def merge_sorted_runs(runs, sid_bits: int, off_bits: int, segment_rows: int = 1 
     return segs
 
 
+# ---- the exchange rounds of the gathered build, stated on the host (csrc/shz_build.hip: gx_round) -------------------
+GX_MAXR, GX_HDR = 16, 8
+GX_BLOCK = GX_HDR + 2 * GX_MAXR      # u64 words a rank contributes to a round
+GXF_GENERAL, GXF_MORE, GXF_FINISHING, GXF_CUT, GXF_HOLDS_RUNS, GXF_STAGED, GXF_BROKEN = 1, 2, 4, 8, 16, 32, 64
+RUN_ROWS_MAX = (1 << 32) - 4096
+
+
+def layout_for(max_sid: int, max_off: int, prev_off_bits: int = 0):
+    """(sid_bits, off_bits) every rank packs in, or None when song id + offset need more than 32 bits: a pure function
+    of the largest offset seen so far (run_layout) -- ranks that saw the same global maxima pack alike."""
+    ob = max(int(max_off).bit_length() or 1, prev_off_bits)
+    return (32 - ob, ob) if (int(max_sid).bit_length() or 1) + ob <= 32 else None
+
+
+class GatherRounds:
+    """Host-side statement of the exchange rounds shz_table_exchange_run / shz_table_allgather run on the device: the same
+    320-byte blocks, the same verdicts, the same termination rule, with ``allgather(obj) -> list`` (any collective that
+    returns every rank's object in rank order) in place of RCCL and numpy arrays in place of the run arena.  It is what
+    the multi-process CPU tests run (gloo), and the specification the device code is read against.
+
+    ``seal(key, sid, off)`` makes a sorted run of this rank's rows; ``exchange()`` is one round (runs not yet sent
+    travel); ``finish()`` runs rounds until every rank is finishing and has nothing left, and returns the merged table.
+    """
+
+    def __init__(self, rank: int, world: int, allgather, run_rows: int = RUN_ROWS_MAX):
+        self.rank, self.world, self.allgather = rank, world, allgather
+        self.run_rows = min(int(run_rows), RUN_ROWS_MAX)
+        self.max_sid = self.max_off = 0
+        self.ob = 0
+        self.local = []        # rows of runs made here and not yet sent: (key, sid, off) triples, sorted
+        self.held = []         # every run this rank holds (its own that travelled, its peers'), as triples
+        self.rounds = 0
+
+    def seal(self, key, sid, off):
+        key, sid, off = (np.asarray(a, np.uint32) for a in (key, sid, off))
+        if len(key) == 0:
+            return
+        self.max_sid, self.max_off = max(self.max_sid, int(sid.max())), max(self.max_off, int(off.max()))
+        for lo in range(0, len(key), self.run_rows):   # a run holds < 2^32 rows: more become several runs
+            k, s_, o = key[lo:lo + self.run_rows], sid[lo:lo + self.run_rows], off[lo:lo + self.run_rows]
+            idx = np.lexsort((o, s_, k))
+            rows = np.unique(np.stack([k[idx], s_[idx], o[idx]], 1), axis=0)   # INSERT IGNORE inside the run
+            self.local.append((rows[:, 0], rows[:, 1], rows[:, 2]))
+
+    def _block(self, finishing: bool, general: bool, pending: bool, st_sid: int = 0, st_off: int = 0):
+        ship = self.local[:GX_MAXR]
+        blk = np.zeros(GX_BLOCK, np.uint64)
+        blk[0] = len(self.local)
+        blk[1], blk[2] = max(self.max_sid, st_sid), max(self.max_off, st_off)
+        blk[4] = (GXF_GENERAL if general else 0) | (GXF_MORE if len(self.local) > len(ship) or pending else 0) | \
+                 (GXF_FINISHING if finishing else 0) | (GXF_HOLDS_RUNS if self.local or self.held else 0)
+        blk[5] = len(ship)
+        for j, r in enumerate(ship):
+            blk[GX_HDR + 2 * j] = len(r[0])
+            blk[GX_HDR + 2 * j + 1] = int(r[1].min()) | (int(r[1].max()) << 32)
+        return blk, ship
+
+    def round(self, finishing: bool, general: bool = False, pending: bool = False, st_sid: int = 0, st_off: int = 0):
+        blk, ship = self._block(finishing, general, pending, st_sid, st_off)
+        got = self.allgather((blk, ship))          # (the device ships the block first, the runs after the verdict)
+        self.rounds += 1
+        blocks = [g[0] for g in got]
+        v = {"any_general": any(int(b[4]) & GXF_GENERAL for b in blocks), "any_more": any(int(b[4]) & GXF_MORE for b in blocks),
+             "any_runs": any(int(b[4]) & GXF_HOLDS_RUNS for b in blocks),
+             "all_finishing": all(int(b[4]) & GXF_FINISHING for b in blocks),
+             "rows_sent": sum(int(b[GX_HDR + 2 * j]) for b in blocks for j in range(int(b[5])))}
+        gmax_sid, gmax_off = max(int(b[1]) for b in blocks), max(int(b[2]) for b in blocks)
+        lay = layout_for(gmax_sid, gmax_off, self.ob)
+        if lay is None:
+            v["any_general"] = True
+        if v["any_general"]:
+            return v
+        self.ob = lay[1]
+        self.max_sid, self.max_off = max(self.max_sid, gmax_sid), max(self.max_off, gmax_off)
+        for r, (b, runs) in enumerate(got):
+            assert len(runs) == int(b[5]) and all(len(x[0]) == int(b[GX_HDR + 2 * j]) < RUN_ROWS_MAX for j, x in enumerate(runs))
+            self.held.extend(runs)                  # a rank's own runs stay where they are; its peers' arrive
+        self.local = self.local[len(ship):]
+        return v
+
+    def exchange(self):
+        v = self.round(False)
+        if v["any_general"]:
+            raise RuntimeError("a rank's rows cannot travel as packed runs")
+        return v
+
+    def finish(self, staged=None):
+        """staged: (key, sid, off) rows not yet sealed.  Returns the merged table (key, sid, off), or raises when the
+        ranks' tables would differ (the device returns SHZ_E_STATE on every rank)."""
+        n_st = 0 if staged is None else len(staged[0])
+        st_sid = int(np.max(staged[1])) if n_st else 0
+        st_off = int(np.max(staged[2])) if n_st else 0
+        general = n_st > 0 and layout_for(max(self.max_sid, st_sid), max(self.max_off, st_off), self.ob) is None
+        v = self.round(True, general, pending=n_st > 0, st_sid=st_sid, st_off=st_off)   # nothing sealed here yet
+        if v["any_general"]:
+            if v["any_runs"]:
+                raise RuntimeError("column path needed while sealed runs wait on some rank")
+            parts = self.allgather(staged if n_st else (np.zeros(0, np.uint32),) * 3)   # the column path: staged rows travel
+            return merge_rows(parts)
+        if n_st:
+            self.seal(*staged)
+        while not (v["all_finishing"] and not v["any_more"]):
+            v = self.round(True)
+            if v["any_general"]:
+                raise RuntimeError("a rank turned to the column path after runs had travelled")
+        sb, ob = 32 - self.ob, self.ob
+        runs = [pack_rows(k, s_, o, sb, ob) for k, s_, o in self.held]
+        segs = merge_sorted_runs(runs, sb, ob, segment_rows=1 << 62) if runs else []
+        return segs[0] if segs else (np.zeros(0, np.uint32),) * 3
+
+
 class ShardedBuilder:
     """Fingerprints this rank's block of tracks on its GPU and builds the node-global table.
 
