@@ -74,6 +74,7 @@ enum {
   SHZ_WS_VT0, SHZ_WS_VT1, SHZ_WS_VT2, SHZ_WS_VT3,   // vote tiles: tile starts, candidate records
   SHZ_WS_VT4,        // table of the vote passes
   SHZ_WS_VT5,        // sub-group of every expand chunk's first vote (expand by sort blocks)
+  SHZ_WS_VT6,        // the bar of every query of a vote pass (vt_stream2_kernel)
   SHZ_WS_COUNT
 };
 

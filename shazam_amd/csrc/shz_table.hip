@@ -1603,6 +1603,264 @@ __global__ __launch_bounds__(64) void vt_stream_kernel(const uint32_t* __restric
   }
 }
 
+// ---- the same tile, filter first (round 4).  What decides a query's top-n are the (song, delta) pairs that many votes
+// agree on; of the ~140 votes of a batch (a group of 16 songs against 1M songs: ~9 votes a song over ~1,000 deltas) nearly
+// all are alone with their pair or share it with one other.  vt_stream_kernel pays two compare-and-swap probe chains, a
+// 64-bit maximum and a table scan for every one of them, and is bound by instruction issue (171 vector + 211 scalar
+// instructions per row of 64 votes, both ports ~70 % busy: profiles/r03f_pmc_match.json).  Here a batch first goes through
+// a KEYLESS COUNTING FILTER: table 1's 4 KB as 4,096 eight-bit counters, one ds_add_rtn per vote on the counter its
+// (song | delta) hashes to.  A counter is an upper bound of the count of every pair that maps to it -- never below -- so
+// "no counter of the batch reached the bar" proves that no pair of the batch did: the batch is finished, with no probe
+// loop, no key compare, no per-lane state (the test is one compare per row, OR-ed into a scalar mask).
+// The bar is the larger of the tile's own n-th candidate and the QUERY's bar: every tile publishes its n-th candidate
+// (atomicMax on a word per query), and the n-th best of any subset of a query's songs is a lower bound of the n-th best of
+// all of them -- a song below it is not in the query's top-n whatever its tile's list holds.  So a tile does not climb from
+// zero: after a query's first tiles the bar stands at the noise ceiling.  A batch that MAY reach it (no bar yet; a counter
+// got there -- by a real pair or by pairs sharing a counter; the filter says nothing about ties, so "reached" includes
+// "equalled") is read again and folded by the exact code of vt_stream_kernel: every candidate's count, smallest delta
+// and row sum come from there, so the results are the same arrays (which tile reports a song, and whether a tile reports
+// songs that end below the final top-n, depends on timing; the ranking of vt_rank_kernel does not).
+__device__ __forceinline__ uint64_t vt_wave_max64(uint64_t v) {
+  const uint32_t h = vt_wave_max((uint32_t)(v >> 32));
+  const uint32_t l = vt_wave_max((uint32_t)(v >> 32) == h ? (uint32_t)v : 0u);
+  return ((uint64_t)h << 32) | l;
+}
+// counter of a (song | delta) key, 12 bits: the multiply is 24-bit (full rate); the bits above 24 are folded in first
+#define VW_FILTER_MAX 200u     // a counter that gets here sends its batch to the exact fold whatever the bar (8 bits wrap at 256)
+__device__ __forceinline__ uint32_t vw_hash_filter(uint32_t x) { return (__umul24((x ^ (x >> 13)) & 0xFFFFFFu, 0x9E3779u) >> 11) & 4095u; }
+static_assert(VW_S1 * 8 == 4096, "table 1 (keys + counts) is 4 KB: 4,096 eight-bit counters");
+
+template <int VW_B2>
+__global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restrict__ k, const uint32_t* __restrict__ tile_start,
+                                                        vt_plan pl, uint32_t topn, uint64_t* __restrict__ c_pack,
+                                                        uint32_t* __restrict__ c_delta, uint32_t* __restrict__ c_dedup,
+                                                        uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy,
+                                                        uint32_t* __restrict__ heavy_q, uint32_t heavy_cap,
+                                                        uint32_t probe_limit, unsigned long long* __restrict__ qbar,
+                                                        uint32_t* __restrict__ err, unsigned long long* __restrict__ stats) {
+  constexpr int VW_S2 = 1 << VW_B2;
+  constexpr uint32_t VW_LIMIT2 = VW_S2 - 68;        // + one row of new songs stays below VW_S2
+  static_assert(VW_LIMIT2 + 64 < (uint32_t)VW_S2 && VW_LIMIT1 + 64 < VW_S1, "a probe must find a free slot in either table");
+  uint32_t st_b = 0, st_over = 0, st_seed = 0, st_beat = 0, st_votes_redo = 0;   // SHZ_VT_STATS
+  __shared__ uint4 t1[VW_S1 / 2];                    // key1[VW_S1] | cnt[VW_S1]
+  __shared__ uint4 t2[VW_S2];                        // key2[VW_S2] | ded[VW_S2] | best[VW_S2] (8 bytes each)
+  uint32_t* const key1 = (uint32_t*)t1;
+  uint32_t* const cnt = key1 + VW_S1;
+  uint32_t* const key2 = (uint32_t*)t2;
+  uint32_t* const ded = key2 + VW_S2;
+  unsigned long long* const best = (unsigned long long*)(ded + VW_S2);
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  const uint32_t a = tile_start[g], b = tile_start[g + 1];
+  const uint32_t dmask = (1u << pl.dbits) - 1u, smask = (pl.sb >= 32 ? ~0u : (1u << pl.sb) - 1u);
+  uint64_t cp = 0;                                   // lane n < topn: candidate n of this tile
+  uint32_t cdl = 0, cdd = 0;
+  auto clear1 = [&]() {                              // table 1
+#pragma unroll
+    for (int i = 0; i < VW_S1 / 4 / 64; ++i) t1[lane + 64 * i] = make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY);
+#pragma unroll
+    for (int i = 0; i < VW_S1 / 4 / 64; ++i) t1[VW_S1 / 4 + lane + 64 * i] = make_uint4(0, 0, 0, 0);
+  };
+  auto clear2 = [&]() {
+#pragma unroll
+    for (int i = 0; i < (VW_S2 + 63) / 64; ++i) {     // key2 (VW_S2 / 4 vectors of EMPTY), then ded and best (zero)
+      const uint32_t e = lane + 64 * i;
+      if (e < VW_S2) t2[e] = e < VW_S2 / 4 ? make_uint4(VT_EMPTY, VT_EMPTY, VT_EMPTY, VT_EMPTY) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto clear_filter = [&]() {                        // table 1 as the filter's counters
+#pragma unroll
+    for (int i = 0; i < VW_S1 / 2 / 64; ++i) t1[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+  };
+  uint32_t* const filt = (uint32_t*)t1;
+  if (a < b) {
+    const uint32_t qi = vt_query_of_tile(pl, g);
+    unsigned long long bar_q = qbar[qi];             // the query's bar as this tile last saw it (it only rises)
+    clear_filter();
+    clear2();                                        // (table 2 is left empty by whoever used it)
+    uint32_t n1 = 0, n2 = 0;                         // wave-uniform (exact fold only)
+    // ---------------- the exact fold of one batch [s, e): vt_stream_kernel's, on a range that is known
+    auto insert = [&](bool act, uint32_t v) {        // whole wave
+      const uint32_t x1[1] = {v >> 1}, x2[1] = {(v >> 1) >> pl.dbits};
+      uint32_t s1[1], s2[1];
+      bool f1[1], f2[1];
+      const bool ok[1] = {act};
+      vt_slots<1, VW_B1, VW_B2>(key1, key2, x1, x2, ok, s1, s2, f1, f2, probe_limit, err);
+      if (act) {
+        const uint32_t c = atomicAdd(&cnt[s1[0]], 1u);
+        atomicMax(&best[s2[0]], ((unsigned long long)(c + 1u) << 32) | (dmask - (x1[0] & dmask)));
+        if (v & 1u) atomicAdd(&ded[s2[0]], 1u);
+      }
+      n2 += (uint32_t)__popcll(__ballot(f2[0]));
+      n1 += (uint32_t)__popcll(__ballot(f1[0]));
+    };
+    auto merge = [&]() {                             // the batch's songs into the running top-n
+      if (n2 == 0) return;
+      constexpr int CE = VW_S2 / 64;                 // every slot of table 2: CE per lane
+      uint64_t pk[CE];
+#pragma unroll
+      for (int u = 0; u < CE; ++u) {
+        const uint32_t s = lane + 64 * u, kk = key2[s];
+        pk[u] = kk == VT_EMPTY ? 0ull : ((best[s] >> 32) << 32) | (0xFFFFFFFFu - (kk & smask));
+      }
+      uint64_t prev = ~0ull, ncp = 0;
+      uint32_t ncdl = 0, ncdd = 0;
+      for (uint32_t n = 0; n < topn; ++n) {
+        uint64_t m = cp < prev ? cp : 0ull;          // (lanes >= topn hold 0)
+        int mu = -1;                                 // entry of m, -1: the old candidate
+#pragma unroll
+        for (int u = 0; u < CE; ++u)
+          if (pk[u] < prev && pk[u] > m) { m = pk[u]; mu = u; }
+        const uint64_t w = vt_wave_max64(m);
+        if (w == 0) break;                           // uniform: nothing ranks below prev
+        const int win = __ffsll((long long)__ballot(m == w)) - 1;   // one lane: packs are unique
+        uint32_t wdl = cdl, wdd = cdd;
+        if ((int)lane == win && mu >= 0) { const uint32_t s = lane + 64 * mu; wdl = dmask - ((uint32_t)best[s] & dmask); wdd = ded[s]; }
+        wdl = (uint32_t)__shfl((int)wdl, win, 64);
+        wdd = (uint32_t)__shfl((int)wdd, win, 64);
+        if (lane == n) { ncp = w; ncdl = wdl; ncdd = wdd; }
+        prev = w;
+      }
+      cp = ncp; cdl = ncdl; cdd = ncdd;
+    };
+    auto hand_over = [&](uint32_t s, uint32_t e) {   // [s, e) to vt_fold_kernel
+      if (lane == 0) {
+        const uint32_t idx = atomicAdd(n_heavy, 1u);
+        if (idx < heavy_cap) { heavy[idx] = make_uint2(s, e); heavy_q[idx] = qi; }
+        else atomicOr(err, 4u);                      // no room in the list: the range's votes would be lost -> the pass is repeated
+      }
+    };
+    auto nth_own = [&]() -> uint64_t {
+      const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cp >> 32), (int)topn - 1);
+      const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cp, (int)topn - 1);
+      return ((uint64_t)h << 32) | l;
+    };
+    auto exact_batch = [&](uint32_t s, uint32_t e) { // table 2 empty on entry and on return; table 1 is handed back as the filter
+      clear1();
+      n1 = n2 = 0;
+      bool over = false;
+      for (uint32_t base = s; base < e && !over; base += 64) {
+        const uint32_t i = base + lane;
+        const bool act = i < e;
+        insert(act, act ? k[i] : 0u);
+        over = n1 > VW_LIMIT1 || n2 > VW_LIMIT2;
+      }
+      if (over) hand_over(s, e); else merge();
+      clear_filter();
+      clear2();
+      // the tile's n-th candidate raises the query's bar for every tile still running; and this tile looks at the bar again
+      const uint64_t mine = nth_own();
+      if (mine > bar_q) {
+        unsigned long long seen = 0;
+        if (lane == 0) seen = atomicMax(&qbar[qi], (unsigned long long)mine);
+        seen = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seen >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
+        bar_q = seen > mine ? seen : mine;
+      }
+    };
+    // ---------------- the stream
+    uint32_t batch_start = a, batch_votes = 0, last_hi = 0xFFFFFFFFu;   // wave-uniform
+    unsigned long long hit = 0;                      // wave-uniform: lanes whose counter reached the bar in this batch
+    uint32_t cm = 0;                                 // per lane: the largest counter value it saw in this batch
+    uint32_t cur_hi = 0;                             // the ordered bits of the batch's first vote
+    uint32_t thr = 2u;                               // a counter at or above this sends the batch to the exact fold
+    uint64_t own = 0;                                // the tile's n-th candidate (0: the list is not full)
+    const int slb = pl.g_lo - 1 - pl.dbits;          // bits of a song id below the ordered ones: song id >= (hi << slb)
+    auto set_thr = [&](uint32_t first_hi) {          // first_hi: the ordered bits of the batch's first vote
+      cur_hi = first_hi;
+      own = nth_own();
+      const uint64_t bar = own > bar_q ? own : bar_q;
+      uint32_t barc = (uint32_t)(bar >> 32);
+      // a pair that only EQUALS the bar's count wins on the smaller song id: never, when every id of the batch (ids ascend
+      // along a tile, and tile after tile) lies above the bar's song -- then a counter must EXCEED the bar's count
+      const uint32_t bar_sid = 0xFFFFFFFFu - (uint32_t)bar;
+      if (barc != 0u && ((uint64_t)first_hi << slb) > (uint64_t)bar_sid) ++barc;
+      thr = barc < 2u ? 2u : (barc > VW_FILTER_MAX ? VW_FILTER_MAX : barc);   // (count 1 is not the filter's business: see end_batch)
+    };
+    auto end_batch = [&](uint32_t e, uint32_t next_hi) {   // next_hi: the ordered bits of the vote at e (the next batch's first)
+      ++st_b;
+      bool redo = hit != 0ull;
+      if (redo) {
+        // the query's bar has risen since this tile last looked (all tiles of a query start together, with no bar at all):
+        // look again before paying for the exact fold -- the lanes' largest counters are tested against the new threshold
+        unsigned long long now = 0;
+        if (lane == 0) now = __hip_atomic_load(&qbar[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        now = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(now >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)now);
+        if (now > bar_q) {
+          bar_q = now;
+          set_thr(cur_hi);
+          redo = __ballot(cm >= thr) != 0ull;
+        }
+      }
+      st_beat += redo;
+      if (!redo && (own > bar_q ? own : bar_q) < (2ull << 32)) {
+        // no pair of the batch has a second vote, and songs of count 1 may still enter: not below the tile's OWN earlier
+        // batches (ids ascend inside a tile), but below another tile's count-1 bar they may
+        redo = own == 0 || bar_q > own;
+        st_seed += redo;
+      }
+      if (redo) { st_votes_redo += e - batch_start; exact_batch(batch_start, e); }
+      else clear_filter();
+      set_thr(next_hi);
+      hit = 0ull;
+      cm = 0;
+      batch_start = e;
+      batch_votes = 0;
+    };
+    // one row's votes of the lanes `act` through the filter: +1 on the counter of (song | delta); lanes outside add nothing
+    auto fast_insert = [&](bool act, uint32_t v) {
+      const uint32_t h = vw_hash_filter(v >> 1), sh = (h & 3u) << 3;
+      const uint32_t old = atomicAdd(&filt[h >> 2], act ? 1u << sh : 0u);
+      const uint32_t c = act ? ((old >> sh) & 0xFFu) + 1u : 0u;
+      cm = c > cm ? c : cm;
+      hit |= __ballot(c >= thr);
+    };
+    uint32_t r0, r1, r2, r3;                         // the next four rows of votes: loads in flight
+    { uint32_t i = a + lane; r0 = i < b ? k[i] : 0u; i += 64; r1 = i < b ? k[i] : 0u; i += 64; r2 = i < b ? k[i] : 0u; i += 64; r3 = i < b ? k[i] : 0u; }
+    for (uint32_t base = a; base < b; base += 64) {
+      const uint32_t v = r0;
+      r0 = r1; r1 = r2; r2 = r3;
+      { const uint32_t i = base + 256 + lane; r3 = i < b ? k[i] : 0u; }
+      const bool valid = base + lane < b;
+      const uint32_t hi = v >> pl.g_lo;
+      const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)last_hi, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      const unsigned long long mg = __ballot(valid && hi != hp);     // lanes that open a group
+      last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);    // (the last row is the only partial one)
+      if (base == a) set_thr((uint32_t)__builtin_amdgcn_readfirstlane((int)hi));
+      if (mg == 0ull || batch_votes < pl.flush) {                    // no border in the row, or none that may end the batch (it is
+        // still below its flush size when the row begins: the whole row joins it, as in vt_stream_kernel): one piece
+        fast_insert(valid, v);
+        batch_votes += (uint32_t)__popcll(__ballot(valid));
+        continue;
+      }
+      uint32_t lo = 0;                               // first lane of the row not dealt with yet
+      while (lo < 64) {                              // uniform
+        const unsigned long long rest = mg & ~((1ull << lo) - 1ull);
+        uint32_t cut = 64;                           // the batch may end at the next group border once it is large enough
+        if (batch_votes >= pl.flush && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
+        if (cut == lo) { end_batch(base + lo, (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)lo)); continue; }
+        const bool act = valid && lane >= lo && lane < cut;
+        fast_insert(act, v);
+        batch_votes += (uint32_t)__popcll(__ballot(act));
+        if (cut < 64) end_batch(base + cut, (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)cut));
+        lo = cut;
+      }
+    }
+    end_batch(b, 0xFFFFFFFFu);
+    if (stats && lane == 0) {
+      atomicAdd(stats + 0, (unsigned long long)st_b); atomicAdd(stats + 1, (unsigned long long)st_over);
+      atomicAdd(stats + 2, (unsigned long long)st_seed); atomicAdd(stats + 3, (unsigned long long)st_beat);
+      atomicAdd(stats + 6, (unsigned long long)st_votes_redo); atomicAdd(stats + 7, (unsigned long long)(b - a));
+    }
+  }
+  if (lane < topn) {
+    const uint64_t o = (uint64_t)g * topn + lane;
+    c_pack[o] = cp;
+    c_delta[o] = cdl;
+    c_dedup[o] = cdd;
+  }
+}
+
 // one query whose votes one workgroup can fold as they come out of the expand (no radix pass at all): the whole pass is
 // the one range handed to vt_fold_kernel
 __global__ void vt_one_range_kernel(uint32_t* __restrict__ n_heavy, uint2* __restrict__ heavy, uint32_t* __restrict__ heavy_q,
@@ -1805,18 +2063,47 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
   const int slb_ = pl.g_lo - 1 - mbp.dbits;
   const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(max_sid, 1u));
   static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
-  if (no_qr)
+  static const int vt_fast = [] { const char* e = getenv("SHZ_VT_FAST"); return e ? atoi(e) : 1; }();   // 0: the fold of round 3 (A/B)
+  const bool few_songs = (double)(1u << slb_) + (double)pl.flush / per_song <= 40.0;
+  const uint32_t plim = vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1;
+  static const bool vt_stats = [] { const char* e = getenv("SHZ_VT_STATS"); return e && atoi(e) != 0; }();
+  unsigned long long* d_stats = nullptr;
+  if (vt_stats) {
+    void* p;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, 64, &p));
+    d_stats = (unsigned long long*)p;
+    SHZ_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, ctx->stream));
+  }
+  unsigned long long* d_qbar = nullptr;   // the bar of every query of the pass (its tiles' n-th candidates, atomicMax)
+  if (vt_fast && !no_qr) {
+    void* p;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT6, 8ull * (VT_MAXQ + 1), &p));
+    d_qbar = (unsigned long long*)p;
+    SHZ_HIP(ctx, hipMemsetAsync(d_qbar, 0, 8ull * (VT_MAXQ + 1), ctx->stream));
+  }
+  if (vt_fast && !no_qr) {
+    if (few_songs)
+      hipLaunchKernelGGL(vt_stream2_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                         (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap, plim, d_qbar, d_vt_err, d_stats);
+    else
+      hipLaunchKernelGGL(vt_stream2_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
+                         (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap, plim, d_qbar, d_vt_err, d_stats);
+  } else if (no_qr)
     hipLaunchKernelGGL((vt_stream_kernel<7, false>), dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
-  else if ((double)(1u << slb_) + (double)pl.flush / per_song <= 40.0)
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap, plim, d_vt_err);
+  else if (few_songs)
     hipLaunchKernelGGL(vt_stream_kernel<7>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap, plim, d_vt_err);
   else
     hipLaunchKernelGGL(vt_stream_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, ks, (const uint32_t*)tile_start, pl, topn,
-                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap,
-                       vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1, d_vt_err);
+                       (uint64_t*)cp, (uint32_t*)cd, (uint32_t*)cdd, n_heavy, heavy, heavy_q, hcap, plim, d_vt_err);
+  if (d_stats) {
+    unsigned long long h[8];
+    SHZ_HIP(ctx, hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[vt_stats] tiles %u few_songs %d batches %llu overflow %llu count1 %llu beat %llu votes_redone %llu votes %llu\n",
+            nt, (int)few_songs, h[0], h[1], h[2], h[3], h[6], h[7]);
+  }
   hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
                      dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
                      (uint64_t*)cp + (uint64_t)nt * topn, (uint32_t*)cd + (uint64_t)nt * topn,
