@@ -1815,12 +1815,29 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
       cm = c > cm ? c : cm;
       hit |= __ballot(c >= thr);
     };
-    uint32_t r0, r1, r2, r3;                         // the next four rows of votes: loads in flight
-    { uint32_t i = a + lane; r0 = i < b ? k[i] : 0u; i += 64; r1 = i < b ? k[i] : 0u; i += 64; r2 = i < b ? k[i] : 0u; i += 64; r3 = i < b ? k[i] : 0u; }
+    // the same in two halves: a whole row's update is ISSUED, and its counter values are looked at one row later -- after
+    // the next row's update has been issued -- so that an LDS round trip is always in flight beside the next row's work
+    uint32_t p_old = 0, p_sh = 0;
+    bool p_any = false;                              // wave-uniform: a row's values are still to be looked at
+    auto consume = [&]() {
+      if (!p_any) return;
+      const uint32_t c = ((p_old >> p_sh) & 0xFFu) + 1u;   // (only whole rows are deferred: every lane took part)
+      cm = c > cm ? c : cm;
+      hit |= __ballot(c >= thr);
+      p_any = false;
+    };
+    // the next VW_AHEAD rows of votes: loads in flight.  The wave waits for memory, not for issue slots (SQ counters: 90 % of
+    // its cycles) -- 26 waves a CU with 4 rows each in flight are 6.8 MB on the whole chip, what ~3 us of loaded latency
+    // turn into ~2 TB/s at best
+    constexpr int VW_AHEAD = 8;
+    uint32_t rr[VW_AHEAD];
+#pragma unroll
+    for (int j = 0; j < VW_AHEAD; ++j) { const uint32_t i = a + lane + 64u * j; rr[j] = i < b ? k[i] : 0u; }
     for (uint32_t base = a; base < b; base += 64) {
-      const uint32_t v = r0;
-      r0 = r1; r1 = r2; r2 = r3;
-      { const uint32_t i = base + 256 + lane; r3 = i < b ? k[i] : 0u; }
+      const uint32_t v = rr[0];
+#pragma unroll
+      for (int j = 0; j + 1 < VW_AHEAD; ++j) rr[j] = rr[j + 1];
+      { const uint32_t i = base + 64u * VW_AHEAD + lane; rr[VW_AHEAD - 1] = i < b ? k[i] : 0u; }
       const bool valid = base + lane < b;
       const uint32_t hi = v >> pl.g_lo;
       const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)last_hi, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
@@ -1829,10 +1846,20 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
       if (base == a) set_thr((uint32_t)__builtin_amdgcn_readfirstlane((int)hi));
       if (mg == 0ull || batch_votes < pl.flush) {                    // no border in the row, or none that may end the batch (it is
         // still below its flush size when the row begins: the whole row joins it, as in vt_stream_kernel): one piece
-        fast_insert(valid, v);
-        batch_votes += (uint32_t)__popcll(__ballot(valid));
+        if (base + 64u <= b) {                                       // a whole row: issued now, looked at with the next row
+          const uint32_t h = vw_hash_filter(v >> 1), sh = (h & 3u) << 3;
+          const uint32_t old = atomicAdd(&filt[h >> 2], 1u << sh);
+          consume();
+          p_old = old; p_sh = sh; p_any = true;
+          batch_votes += 64u;
+        } else {
+          consume();
+          fast_insert(valid, v);
+          batch_votes += b - base;
+        }
         continue;
       }
+      consume();
       uint32_t lo = 0;                               // first lane of the row not dealt with yet
       while (lo < 64) {                              // uniform
         const unsigned long long rest = mg & ~((1ull << lo) - 1ull);
@@ -1846,6 +1873,7 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
         lo = cut;
       }
     }
+    consume();
     end_batch(b, 0xFFFFFFFFu);
     if (stats && lane == 0) {
       atomicAdd(stats + 0, (unsigned long long)st_b); atomicAdd(stats + 1, (unsigned long long)st_over);
@@ -2016,14 +2044,23 @@ static void vt_make_plan(const uint64_t* counts, uint32_t nqp, const m_bits& mbp
   pl.dbits = mbp.dbits;
   pl.sb = mbp.sb;
   pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
-  pl.tile = VW_CHUNK;
+  // votes per tile: a tile pays a fixed price (its place in the plan, the query's bar, the first loads' latency, its
+  // candidates' way through vt_rank_kernel) that 2,048 votes do not amortise -- 1M songs, batches of 200: 0.147 ms a query at
+  // 2,048, 0.141 at 4,096, 0.138 at 8,192, 0.136 at 16,384 -- but the chip wants ~2 rounds of tiles (256 CUs x 26 waves)
+  static const uint32_t chunk_env = [] { const char* e = getenv("SHZ_VW_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1024 && v <= 65536 ? (uint32_t)v : 0u; }();
+  uint64_t all_votes = 0;
+  for (uint32_t i = 0; i < nqp; ++i) all_votes += counts[i];
+  uint32_t chunk = VW_CHUNK;
+  while (chunk < 16384u && all_votes / (2ull * chunk) >= 13312ull) chunk *= 2;
+  if (chunk_env) chunk = chunk_env;
+  pl.tile = chunk;
   static const uint32_t flush_env = [] { const char* e = getenv("SHZ_VW_FLUSH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : 0u; }();
   pl.flush = flush_env ? flush_env : VW_FLUSH;
   pl.qv[0] = pl.tb[0] = sp.qv[0] = sp.bq[0] = 0;
   for (uint32_t i = 0; i < nqp; ++i) {
     const uint64_t c = counts[i];
     pl.qv[i + 1] = sp.qv[i + 1] = pl.qv[i] + (uint32_t)c;
-    pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + VW_CHUNK - 1) / VW_CHUNK);
+    pl.tb[i + 1] = pl.tb[i] + (uint32_t)((c + chunk - 1) / chunk);
     sp.bq[i + 1] = sp.bq[i] + (uint32_t)((c + 4095) / 4096);   // (the sort fills in its own block size)
   }
   for (uint32_t i = nqp; i < VT_MAXQ; ++i) {
@@ -2043,7 +2080,7 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
   const uint32_t nqp = pl.nq;
   const int Bt = mbp.sb + mbp.dbits + 1;
   const uint32_t vt_probe_limit_1 = (ctx->debug & SHZ_DEBUG_VT_PROBE1) ? 1u : 0u;   // debug: a probe gives up after one round
-  const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * VW_HEAVY_PER_TILE;
+  const uint32_t nt = pl.tb[nqp], hcap = (ctx->debug & SHZ_DEBUG_VT_TINY_HEAVY) ? 1u : nt * (VW_HEAVY_PER_TILE * ((pl.tile + VW_CHUNK - 1) / VW_CHUNK));
   int sel = 0;
   SHZ_TRY(shz_sort_u32_seg(ctx, k32, k32_alt, pp, pl.g_lo, Bt, sp, &sel, hist0));
   const uint32_t* ks = sel ? k32_alt : k32;
