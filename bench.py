@@ -157,6 +157,88 @@ def cpu_baseline(n_samples, budget_s=15.0):
             "hashes_per_clip": float(np.mean([r[1] for r in res]))}
 
 
+def match_cpu_baseline(tbl, k, t1, ho, gpu_res, songs, budget_s=12.0, topn=2):
+    """CPU baseline of the match half of the metric ("p50/p99 ms per query with an in-memory dict table
+    standing in for MySQL"): the reference's return_matches + align_matches (recognizer.py:222-338, restated in
+    oracle/cpu_ref.py and pinned to the reference's goldens) over the SAME table and the SAME queries, one core -- the
+    reference's matcher is a single-threaded Python loop over the rows MySQL returns.  The table is this step's rows exported
+    from the GPU and indexed by a dict hash -> row range (the B-tree on `hash`, mysql_database.py:46-59).  Beside it a numpy
+    sorted-array matcher (searchsorted + unique) as the fastest thing numpy does on one core.  Bounded: queries until the
+    budget is spent."""
+    from oracle import cpu_ref as O
+    t0 = time.perf_counter()
+    key, sid, off = tbl.export()
+    if len(key) > 1 and not np.all(key[1:] >= key[:-1]):   # several segments: one sorted table for the host index
+        order = np.lexsort((off, sid, key))
+        key, sid, off = key[order], sid[order], off[order]
+    uk, start, cnt = np.unique(key, return_index=True, return_counts=True)
+    index = dict(zip(uk.tolist(), zip(start.tolist(), (start + cnt).tolist())))
+    sid_l, off_l = sid.tolist(), off.tolist()
+    per_song = np.bincount(sid, minlength=songs + 2)
+    t_index = time.perf_counter() - t0
+
+    class ArrayDB:   # the duck-typed surface the oracle's matcher uses
+        def select_multiple(self, values):
+            for h in values:
+                se = index.get(h)
+                if se:
+                    for i in range(se[0], se[1]):
+                        yield h, sid_l[i], off_l[i]
+
+        def get_song_by_id(self, s_):
+            return {"song_name": f"track{s_}", "total_hashes": int(per_song[s_]), "file_sha1": "0" * 40}
+
+    db = ArrayDB()
+
+    def numpy_match(qk, qo):
+        q = np.unique((qk.astype(np.uint64) << np.uint64(32)) | qo.astype(np.uint64))   # set(hashes)
+        qk, qo = (q >> np.uint64(32)).astype(np.uint32), (q & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        lo, hi = np.searchsorted(key, qk, "left"), np.searchsorted(key, qk, "right")
+        n = hi - lo
+        rows = np.repeat(lo, n) + (np.arange(n.sum()) - np.repeat(np.cumsum(n) - n, n))
+        s_ = sid[rows].astype(np.int64)
+        d = off[rows].astype(np.int64) - np.repeat(qo, n)
+        pairs, c = np.unique((s_ << 32) | (d + (1 << 20)), return_counts=True)
+        ps = pairs >> 32
+        first = np.r_[True, ps[1:] != ps[:-1]]
+        grp = np.cumsum(first) - 1
+        best = np.zeros(grp[-1] + 1 if len(grp) else 0, np.int64)
+        np.maximum.at(best, grp, c)
+        order = np.argsort(-best, kind="stable")[:topn]
+        return [int(ps[first][i]) for i in order]
+
+    lat = {"dict": [], "numpy": []}
+    agree = {"dict": 0, "numpy": 0}
+    nq_done = 0
+    t_begin = time.perf_counter()
+    for q in range(len(ho) - 1):
+        qk, qo = k[int(ho[q]):int(ho[q + 1])], t1[int(ho[q]):int(ho[q + 1])]
+        hashes = set(zip(qk.tolist(), qo.tolist()))          # recognizer.py:378-382
+        t0 = time.perf_counter()
+        matches, dedup = O.return_matches(hashes, db)
+        res = O.align_matches(matches, dedup, len(hashes), db, topn)
+        t1_ = time.perf_counter()
+        top_np = numpy_match(qk, qo)
+        t2 = time.perf_counter()
+        lat["dict"].append(t1_ - t0)
+        lat["numpy"].append(t2 - t1_)
+        want = int(gpu_res["sid"][q, 0]) if gpu_res["nres"][q] else None
+        agree["dict"] += (res[0]["song_id"] if res else None) == want
+        agree["numpy"] += (top_np[0] if top_np else None) == want
+        nq_done += 1
+        if nq_done >= 20 and time.perf_counter() - t_begin > budget_s:
+            break
+    o = {"kind": "port", "cores": 1, "queries": nq_done, "table_rows": int(len(key)), "songs": int(songs), "host_index_build_s": t_index,
+         "sample": f"the first {nq_done} queries of the GPU's own batch against the same {len(key)} rows, one core; dict-table = the "
+                   "oracle's return_matches + align_matches (the reference's Python loop) over a dict hash -> rows; numpy_sorted = "
+                   "searchsorted + unique on the sorted columns"}
+    for name in ("dict", "numpy"):
+        v = np.array(lat[name]) * 1e3
+        o[f"{'dict_table' if name == 'dict' else 'numpy_sorted'}"] = {"p50_ms": float(np.median(v)), "p99_ms": float(np.percentile(v, 99)),
+                                                                     "mean_ms": float(v.mean()), "top1_equals_gpu": int(agree[name])}
+    return o
+
+
 def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elapsed, pcm, out):
     from shazam_amd import _ffi
 
@@ -234,17 +316,49 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
                     "qps": nq / t_match, "fingerprint_ms_per_query": t_fp / nq * 1e3, "top1_correct": correct,
                     "rows_scanned": st["rows_scanned"], "pairs": st["pairs"],
                     "alg_GBs": (8 * st["rows_scanned"] + 16 * st["distinct_keys"]) / t_match / 1e9}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cb = match_cpu_baseline(tbl, k, t1, ho, res, world * nc)
+            cb["gpu_ms_per_query_batched"] = out["match"]["ms_per_query_batched"]
+            cb["gpu_over_cpu_dict_table"] = cb["dict_table"]["mean_ms"] / out["match"]["ms_per_query_batched"]
+            out["match"]["cpu_baseline"] = cb
+        except Exception as e:  # noqa: BLE001
+            out["match"]["cpu_baseline"] = {"error": repr(e)}
     qpcm.free()
-    # the same hot path fed from HOST memory (pageable numpy -> hipMemcpy inside the call): PCIe-inclusive rate
-    nh = min(200, nc)
+    # the same hot path fed from HOST memory -- what every caller of the reference hands over (__init__.py:248-268;
+    # recognizer.py:377-382): PCIe-inclusive rates, never the headline value.  The call cuts the batch into chunks of whole
+    # clips and uploads chunk i + 1 beside the kernels of chunk i (shz_extract.hip: extract_streamed), so its ceiling is the
+    # link: the probes beside it say what the link gives from pinned and from pageable memory on this box.
+    nh = min(400, nc)
     host_pcm = pcm.download(np.int16, nh * n_samples)
     hoff = np.arange(nh + 1, dtype=np.uint64) * n_samples
-    ctx.fingerprint_batch(host_pcm, hoff)
-    t0 = time.perf_counter()
-    ctx.fingerprint_batch(host_pcm, hoff)
-    t_host = time.perf_counter() - t0
-    out["pcie_inclusive"] = {"clips": nh, "audio_s_per_s": nh * n_samples / FS / t_host,
-                             "note": "host int16 PCM in, host (key32,t1) out, pageable memory; never the headline value"}
+    bytes_per_audio_s = 2.0 * FS
+    pi = {"clips": nh, "bytes": int(host_pcm.nbytes), "note": "host int16 PCM in, host (key32,t1) out; never the headline value"}
+    try:
+        probe = {"pinned_h2d_GBs": ctx.membw(3, 512 << 20, 4), "pageable_h2d_GBs": ctx.membw(4, 512 << 20, 4),
+                 "pinned_d2h_GBs": ctx.membw(5, 512 << 20, 4)}
+        pi["link_probe"] = probe
+        pi["ceiling_audio_s_per_s"] = {"pinned": probe["pinned_h2d_GBs"] * 1e9 / bytes_per_audio_s,
+                                       "pageable": probe["pageable_h2d_GBs"] * 1e9 / bytes_per_audio_s}
+    except Exception as e:  # noqa: BLE001
+        pi["link_probe"] = {"error": repr(e)}
+    pinned_pcm = ctx.host_array(len(host_pcm), np.int16)
+    pinned_pcm[:] = host_pcm
+    for name, arr in (("pageable", host_pcm), ("pinned", pinned_pcm)):
+        ctx.fingerprint_batch(arr, hoff)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.fingerprint_batch(arr, hoff)
+            ts.append(time.perf_counter() - t0)
+        t_host = float(np.median(ts))
+        pi[name] = {"audio_s_per_s": nh * n_samples / FS / t_host, "GBs": host_pcm.nbytes / t_host / 1e9, "seconds": t_host}
+        if "ceiling_audio_s_per_s" in pi:
+            pi[name]["frac_of_link_ceiling"] = pi[name]["audio_s_per_s"] / pi["ceiling_audio_s_per_s"][name]
+    pi["audio_s_per_s"] = pi["pinned"]["audio_s_per_s"]
+    pi["upload_pipeline"] = ctx.upload_stats()
+    out["pcie_inclusive"] = pi
+    del pinned_pcm
     # One query at a time through the reference-shaped entry point (host PCM in, result dicts out): serving latency
     try:
         out["single_query"] = single_query_latency(ctx, tbl, rank, nc, n_samples)
@@ -550,12 +664,13 @@ def main():
     tflops = frames_per_launch * FFT_FLOP_PER_FRAME / (avg_ms * 1e-3) / 1e12
     roofline = {"bound": "valu_fp64" if dom == "stft_psd" else "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_from_profile": True,   # a committed rocprofv3 PMC pass of this same command, not of this very run
                 "traffic_unit": f"GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_file})",
                 "compute": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "compute_frac": tflops / FP64_VALU_PEAK_TFLOPS,
                             "accounting": f"{FFT_FLOP_PER_FRAME:.0f} flop/frame (2.5 N log2 N, N = 4096) x {frames_per_launch:.0f} "
                                           f"frames/launch / {avg_ms:.3f} ms; the kernel's own count is higher (window, split pass, |X|^2)",
-                            "valu_busy_frac_pmc": valu_busy,
+                            "valu_busy_frac_pmc": valu_busy, "valu_busy_from_profile": True,
                             "valu_busy_source": f"SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 3 waves per SIMD, profiles/{valu_file}"} if dom == "stft_psd" else None,
                 "accounting": f"algorithmic bytes (SURVEY 8d): {alg_bytes_per_frame:.0f} B/frame (4096 B PCM + 8 B x "
                               f"{n_hashes / frames_per_step:.1f} hashes) x {frames_per_launch:.0f} frames/launch / "

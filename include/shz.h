@@ -101,7 +101,9 @@ int32_t shz_synth_corpus(shz_ctx* ctx, uint32_t kind, uint64_t seed, uint64_t cl
 
 /* HBM bandwidth probe (the measured ceiling beside the vendor peak): mode 0 copy (bytes read +
  * bytes written are counted), 1 read only, 2 write only; two scratch buffers of `bytes` each are allocated and
- * freed inside; gb_per_s = bytes moved / hipEvent time over `iters` launches (16 B per lane, grid-stride). */
+ * freed inside; gb_per_s = bytes moved / hipEvent time over `iters` launches (16 B per lane, grid-stride).
+ * Host link probe (what a host-fed fingerprint call can reach at best): mode 3 pinned host -> device, 4 pageable host ->
+ * device, 5 device -> pinned host; `iters` copies of `bytes`, host clock around them. */
 int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s);
 
 /* The device radix sort the table build and the vote use (tests / tools): stable sort of n 64-bit keys on bits
@@ -127,6 +129,12 @@ int32_t shz_sort_keys32_seg(shz_ctx* ctx, const uint32_t* keys, const uint64_t* 
 int32_t shz_sumsq_i16(shz_ctx* ctx, const int16_t* dev_pcm, uint32_t n_clips, uint64_t n_samples, uint64_t* out_host);
 int32_t shz_mix_i16(shz_ctx* ctx, const int16_t* dev_sig, const int16_t* dev_noise, uint32_t n_clips,
                     uint64_t n_samples, const double* scale_host, int16_t* dev_out);
+
+/* Pinned host memory for PCM (and any other array handed to the library): the reference's callers hold their samples in
+ * host arrays (read(), __init__.py:70-113; recognizer.py:357-382); a decoder that writes them into a buffer from here lets
+ * shz_fingerprint_batch feed the GPU by DMA at the link rate, chunk by chunk beside the kernels of the chunk before. */
+int32_t shz_host_alloc(shz_ctx* ctx, uint64_t bytes, void** out);
+int32_t shz_host_free(shz_ctx* ctx, void* p);   /* ctx may be NULL */
 
 /* ---- extraction --------------------------------------------------------------------- */
 /* Frames mlab produces for n_samples (mlab.specgram via __init__.py:232-237). */
@@ -174,6 +182,12 @@ int32_t shz_pair_hash(shz_ctx* ctx, const uint16_t* peak_f, const uint32_t* peak
 int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
                               uint32_t fs, double amp_min, uint32_t fan_value, uint32_t flags,
                               uint32_t* key32, uint32_t* t1, uint64_t* hash_off, uint64_t cap, uint64_t* count);
+
+/* Host PCM of 192 MB or more (no SHZ_PCM_DEVICE) is fed in chunks of whole clips (16 MB, then ~64 MB): a helper thread uploads chunk
+ * i + 1 on its own stream while the extraction pass of chunk i runs -- the call's rate is the link's.  Results are those of
+ * one pass.  SHZ_UPLOAD_PIPELINE=0 in the environment turns it off.  Counters since the context was created: chunks and
+ * bytes that went that way, seconds the upload thread spent copying, seconds the passes waited for a chunk. */
+int32_t shz_upload_stats(shz_ctx* ctx, uint64_t* chunks, uint64_t* bytes, double* copy_s, double* wait_s);
 
 /* Staging precision of shz_peaks / shz_fingerprint_batch.  Default (0): the power spectrogram is staged in fp32 and
  * the cells fp32 cannot decide (shared window maxima, threshold within 1e-7) are re-derived in fp64; results are

@@ -31,6 +31,8 @@ SIGNATURES = {
     "shz_copy_h2d": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "shz_copy_d2h": (C.c_int32, [vp, vp, vp, C.c_uint64]),
     "shz_sync": (C.c_int32, [vp]),
+    "shz_host_alloc": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),
+    "shz_host_free": (C.c_int32, [vp, vp]),
     "shz_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
     "shz_release_workspace": (C.c_int32, [vp, u64p]),
     "shz_timer_start": (C.c_int32, [vp, C.c_int32]),
@@ -55,6 +57,7 @@ SIGNATURES = {
     "shz_fingerprint_batch": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32,
                                           vp, vp, u64p, C.c_uint64, u64p]),
     "shz_set_stage_f64": (C.c_int32, [vp, C.c_int32]),
+    "shz_upload_stats": (C.c_int32, [vp, u64p, u64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "shz_extract_stats": (C.c_int32, [vp, u64p, u64p, u64p, u64p, u64p, u64p]),
     "shz_sha1_prefix": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "shz_sha1_invert": (C.c_int32, [vp, vp, C.c_uint64, vp]),
@@ -234,6 +237,20 @@ class Context:
     def alloc(self, nbytes) -> DevBuf:
         return DevBuf(self, nbytes)
 
+    def host_array(self, shape, dtype=np.int16) -> np.ndarray:
+        """numpy array in PINNED host memory (shz_host_alloc): PCM decoded into it reaches the GPU by DMA at the link rate.
+        The memory lives as long as the array (and its views' base) does."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = vp()
+        self.check(lib().shz_host_alloc(self.h, max(1, n * dt.itemsize), C.byref(p)))
+        buf = (C.c_char * max(1, n * dt.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+        addr = p.value
+        import weakref
+        weakref.finalize(buf, lambda: lib().shz_host_free(None, vp(addr)))   # (the array may outlive the context)
+        return arr
+
     def sync(self):
         self.check(lib().shz_sync(self.h))
 
@@ -348,6 +365,12 @@ class Context:
         co = np.ascontiguousarray(clip_off, np.uint64)
         assert co.ndim == 1 and len(co) >= 1
         return co, len(co) - 1
+
+    def upload_stats(self) -> dict:
+        """Host PCM that went through the chunked upload pipeline since the context was created."""
+        c, b, cs, ws = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_double()
+        self.check(lib().shz_upload_stats(self.h, C.byref(c), C.byref(b), C.byref(cs), C.byref(ws)))
+        return {"chunks": c.value, "bytes": b.value, "copy_s": cs.value, "wait_s": ws.value}
 
     def set_stage_f64(self, enabled: bool):
         """fp64 staging of the power spectrogram (exact ties decided in the peak kernel) instead of fp32 + verify."""

@@ -3,6 +3,9 @@
 
 #include <algorithm>
 
+#include <time.h>
+#include <stdlib.h>
+
 #include "shz_internal.h"
 
 extern "C" const char* shz_version(void) { return "shz 0.1 (gfx950)"; }
@@ -663,10 +666,53 @@ __global__ __launch_bounds__(256) void membw_kernel(const uint4* __restrict__ sr
   if (mode == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = 1;  // keeps the loads alive
 }
 
+// Pinned host memory for the caller's PCM: a decoder that writes its samples here hands shz_fingerprint_batch a buffer the
+// DMA engines read directly (no staging copy, no page registration per call).
+extern "C" int32_t shz_host_alloc(shz_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out) return SHZ_E_INVALID;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  *out = nullptr;
+  if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_host_alloc: hipHostMalloc(%llu) failed", (unsigned long long)bytes);
+  }
+  return SHZ_OK;
+}
+extern "C" int32_t shz_host_free(shz_ctx* ctx, void* p) {   // ctx may be NULL (a buffer may outlive its context)
+  if (!p) return SHZ_OK;
+  if (hipHostFree(p) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx) SHZ_FAIL(ctx, SHZ_E_HIP, "shz_host_free: hipHostFree failed");
+    return SHZ_E_HIP;
+  }
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_membw(shz_ctx* ctx, int32_t mode, uint64_t bytes, uint32_t iters, float* gb_per_s) {
   if (!ctx || !gb_per_s) return SHZ_E_INVALID;
-  if (mode < 0 || mode > 2 || bytes < (1ull << 20) || iters < 1) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_membw: mode 0..2, >= 1 MiB, >= 1 iteration");
+  if (mode < 0 || mode > 5 || bytes < (1ull << 20) || iters < 1) SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_membw: mode 0..5, >= 1 MiB, >= 1 iteration");
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  if (mode >= 3) {   // the host link: 3 pinned host -> device, 4 pageable host -> device, 5 device -> pinned host (host clock)
+    void *d = nullptr, *h = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_membw: hipMalloc(%llu) failed", (unsigned long long)bytes);
+    if (mode == 4) h = malloc(bytes);
+    else if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) h = nullptr;
+    if (!h) { (void)hipFree(d); SHZ_FAIL(ctx, SHZ_E_NOMEM, "shz_membw: host allocation of %llu bytes failed", (unsigned long long)bytes); }
+    memset(h, 0x5A, bytes);
+    const hipMemcpyKind kd = mode == 5 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    void *dst = mode == 5 ? h : d, *src = mode == 5 ? d : h;
+    hipError_t err = hipMemcpyAsync(dst, src, bytes, kd, ctx->stream);   // warm-up (page faults, first-touch of the staging)
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    const double t0 = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }();
+    for (uint32_t it = 0; it < iters && err == hipSuccess; ++it) err = hipMemcpyAsync(dst, src, bytes, kd, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    const double t1 = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }();
+    (void)hipFree(d);
+    if (mode == 4) free(h); else (void)hipHostFree(h);
+    SHZ_HIP(ctx, err);
+    *gb_per_s = (float)((double)bytes * iters / (t1 - t0) / 1e9);
+    return SHZ_OK;
+  }
   const uint64_t n16 = bytes / 16;
   void *a = nullptr, *b = nullptr, *sink = nullptr;
   if (hipMalloc(&a, n16 * 16) != hipSuccess || hipMalloc(&b, n16 * 16) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) {

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <string>
@@ -31,6 +32,12 @@
     int32_t _s = (expr);               \
     if (_s != SHZ_OK) return _s;       \
   } while (0)
+
+static inline double now_seconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 struct shz_prof_rec;
 // a growable device buffer owned by the ctx (scratch arena slot)
@@ -114,6 +121,9 @@ struct shz_ctx {
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
   hipStream_t stream2 = nullptr;   // second stream of the extraction pipeline (created on first use)
+  hipStream_t stream_up = nullptr; // uploads of host PCM, chunk by chunk beside the kernels of the chunk before (created on first use)
+  uint64_t st_up_chunks = 0, st_up_bytes = 0;   // chunks / bytes that went through that pipeline
+  double st_up_copy_s = 0.0, st_up_wait_s = 0.0;   // seconds the upload thread spent copying / the main thread waited for a chunk
   hipEvent_t ev_stft[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   shz_ctx* twin = nullptr;         // second pipeline of a dual extraction pass: own stream, own workspace (created on first use)
   hipEvent_t ev_twin = nullptr;
