@@ -524,7 +524,8 @@ def match_1m(ctx, songs, info):
     n_samples = 30 * FS
     qn = 10 * FS
     o = {"songs": songs, "rows": build["rows"], "build_seconds": build["seconds_total"],
-         "build": {k: build[k] for k in ("fingerprint_s", "insert_s", "finalize_s", "songs_per_s", "segments", "key_range_segments", "phases_s")},
+         "build": {k: build[k] for k in ("reserve_s", "fingerprint_s", "insert_s", "finalize_s", "synth_wait_s", "synth_overlapped",
+                                         "songs_per_s", "segments", "key_range_segments", "phases_s")},
          "query_seconds": 10.0, "snr_db": 10.0}
     for bs, nq in ((1, 60), (200, 2000)):
         bench_db.run_queries(ctx, tbl, songs, n_samples, bs * 2, qn, 10.0, bs, 2, seed=5)   # warm the workspace

@@ -43,23 +43,31 @@ def synth_tracks(ctx, corpus, c0, nc, n_samples, tone_amp, noise_amp, out, start
 
 
 def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1500, finalize_every=0, shards=1,
-                progress=None, reserve=True, corpus="tonal", hold=True):
+                progress=None, reserve=True, corpus="tonal", hold=True, overlap_synth=False):
     """Synthesise `songs` tracks on the device, fingerprint them in chunks and build one HBM table.
     Every `finalize_every` songs the staged rows are sealed into a sorted run (bounded staging and sort scratch; rows become
     visible at the final finalize).  hold: the table keeps its runs until ONE merge at the end cuts the segments by key
     range (a query hash is then looked up in one segment) -- needs the arena to hold every row beside the columns
     (20 B a row); when that does not fit, full segments are cut on the way as before (every segment spans every key).
+    The table's arenas are reserved on a helper thread beside the first chunks (shz_table_reserve).  Device memory that any
+    process freed comes back scrubbed by the driver at ~43 GB/s (23 ms a GB), and the scrub shares the GPU with the kernels:
+    reserved up front it adds its own time (1M x 30 s, 250 GB: reserve 5.7 s + fingerprint 6.4 s; seconds_total 20.0), beside
+    the first chunks it stretches them instead (fingerprint 8.8 s, seconds_total 16.8) -- the second is what is done.
+    overlap_synth (off): chunk i + 1 synthesised by a second context (own stream, second PCM buffer) while chunk i is
+    fingerprinted and inserted.  Measured at 1M x 30 s: 13.0 s against 6.43 + 6.88 s one after the other -- synthesis and
+    the STFT are both bound by the vector ALU and only share the chip; left off so that fingerprint_s means fingerprinting.
     Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
     from shazam_amd import _ffi, Table
     n_samples = int(round(seconds * FS))
     frames = int(_ffi.lib().shz_frame_count(n_samples))
+    t_build0 = time.perf_counter()   # (the reservation counts: it is part of what a build costs)
     if shards > 1:
         from shazam_amd.shard import ShardedTable
         tbl = ShardedTable(ctx, nshards=shards)
     else:
         tbl = Table(ctx)
         held = False
-        if reserve:   # the table's arenas in one go, allocated beside the first fingerprint batches
+        if reserve:   # the table's arenas in one go, before the first chunk
             per_batch = finalize_every if finalize_every else songs
             rows_hint, batch_hint = int(songs * frames * ROWS_PER_FRAME_HINT), int(min(per_batch, songs) * frames * ROWS_PER_FRAME_HINT)
             if hold:
@@ -73,28 +81,37 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
                     tbl = Table(ctx)
             if not held:
                 tbl.reserve(rows_hint, batch_hint)
+    t_reserve = time.perf_counter() - t_build0
     cap = chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
-    pcm = ctx.alloc(chunk * n_samples * 2)
-    t_fp = t_ins = t_fin = 0.0
+    overlap_synth = overlap_synth and songs > chunk
+    ctx_s = _ffi.Context(ctx.device_id) if overlap_synth else ctx     # synthesis on its own stream
+    pcms = [ctx.alloc(chunk * n_samples * 2) for _ in range(2 if overlap_synth else 1)]
+    t_fp = t_ins = t_fin = t_synth_wait = 0.0
     n_rows_in = 0
-    t_build0 = time.perf_counter()
-    for c0 in range(0, songs, chunk):
+    starts = list(range(0, songs, chunk))
+    synth_tracks(ctx_s, corpus, 0, min(chunk, songs), n_samples, tone_amp, noise_amp, pcms[0])
+    for i, c0 in enumerate(starts):
         nc = min(chunk, songs - c0)
-        synth_tracks(ctx, corpus, c0, nc, n_samples, tone_amp, noise_amp, pcm)
+        pcm = pcms[i % len(pcms)]
         off = np.arange(nc + 1, dtype=np.uint64) * n_samples
-        ctx.sync()
+        t0 = time.perf_counter()
+        ctx_s.sync()                      # chunk i is there
+        t_synth_wait += time.perf_counter() - t0
+        if overlap_synth and i + 1 < len(starts):   # chunk i + 1 into the other buffer (chunk i - 1, its last user, is done)
+            synth_tracks(ctx_s, corpus, starts[i + 1], min(chunk, songs - starts[i + 1]), n_samples, tone_amp, noise_amp, pcms[(i + 1) % 2])
         t0 = time.perf_counter()
         _, _, ho, cnt = ctx.fingerprint_batch(pcm, off, fs=FS, pcm_device=True, out_key=kbuf, out_t1=tbuf, cap=cap)
-        ctx.sync()
         t_fp += time.perf_counter() - t0
         t0 = time.perf_counter()
         tbl.insert_clips(kbuf, tbuf, ho, sid0=1 + c0, device=True)
         t_ins += time.perf_counter() - t0
         n_rows_in += cnt
+        if not overlap_synth and i + 1 < len(starts):
+            synth_tracks(ctx, corpus, starts[i + 1], min(chunk, songs - starts[i + 1]), n_samples, tone_amp, noise_amp, pcm)
         if finalize_every and (c0 + nc) % finalize_every == 0 and c0 + nc < songs:
             t0 = time.perf_counter()
-            tbl.seal_run()        # bounds staged rows + sort scratch; full segments are cut as soon as enough rows wait
+            tbl.seal_run()        # bounds staged rows + sort scratch (held runs wait for the one merge at the end)
             ctx.sync()
             t_fin += time.perf_counter() - t0
             if progress:
@@ -105,8 +122,12 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     t_fin += time.perf_counter() - t0
     t_build = time.perf_counter() - t_build0
     rows, _ = tbl.rows()
-    pcm.free()
-    stats = {"seconds_total": t_build, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
+    for b_ in pcms:
+        b_.free()
+    if ctx_s is not ctx:
+        ctx_s.close()
+    stats = {"seconds_total": t_build, "reserve_s": t_reserve, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
+             "synth_wait_s": t_synth_wait, "synth_overlapped": bool(overlap_synth),
              "rows_inserted": int(n_rows_in), "rows": int(rows), "songs_per_s": songs / t_build,
              "audio_s_per_s": songs * seconds / t_build, "segments": int(tbl.segments()) if shards == 1 else None,
              "key_range_segments": bool(shards == 1 and reserve and held),
@@ -195,6 +216,8 @@ def main():
                     "noise; music: music-like tracks under traffic-like query noise")
     ap.add_argument("--shards", type=int, default=1, help="partition the table by key into this many shards on the GPU "
                     "(shazam_amd/shard.py): measures the cost of per-shard voting + merge against the single table")
+    ap.add_argument("--overlap-synth", action="store_true", help="synthesise the next chunk on a second context beside the fingerprint "
+                    "kernels of this one (measured: no gain, both are bound by the vector ALU)")
     ap.add_argument("--no-hold", action="store_true", help="cut full segments on the way (bounded arena; every segment spans every "
                     "key) instead of holding all runs for one merge into key-range segments")
     a = ap.parse_args()
@@ -203,7 +226,8 @@ def main():
     ctx = _ffi.Context(int(os.environ.get("SHZ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     n_samples = int(round(a.seconds * FS))
     tbl, build, (kbuf, tbuf, cap) = build_table(ctx, a.songs, a.seconds, a.chunk, a.tone_amp, a.noise_amp,
-                                                a.finalize_every, a.shards, corpus=a.corpus, hold=not a.no_hold)
+                                                a.finalize_every, a.shards, corpus=a.corpus, hold=not a.no_hold,
+                                                overlap_synth=a.overlap_synth)
     rows = build["rows"]
 
     qn = int(round(a.query_seconds * FS))
