@@ -288,7 +288,9 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
     # contiguous blocks (ingest.shard_tracks), fingerprint -> RCCL all-gather of the sorted runs -> k-way merge -> table.
     # N = 1 runs the same code with one run and no exchange.  The reference's analogue is the file-level Pool of
     # fingerprint_directory (__init__.py:335-357).
-    if a.scaling_songs > 0:
+    # (one GPU: run after the 1M-song table below -- that one reserves 250 GB beside its first chunks, and on memory nothing in
+    # this process has freed yet the reservation costs nothing; the scaling build reserves outside its clock either way)
+    if a.scaling_songs > 0 and world > 1:
         try:
             out["db_build_scaling"] = db_build_scaling(a, ctx, dist, comm, rank, world)
         except Exception as e:  # noqa: BLE001
@@ -735,6 +737,11 @@ def main():
                 out["match_1M"] = match_1m(ctx, a.match_songs, info)
             except Exception as e:  # noqa: BLE001
                 out["match_1M"] = {"error": repr(e)}
+        if world == 1 and a.scaling_songs > 0:
+            try:
+                out["db_build_scaling"] = db_build_scaling(a, ctx, None, None, 0, 1)
+            except Exception as e:  # noqa: BLE001
+                out["db_build_scaling"] = {"error": repr(e)}
         dog.cancel()
     emit()
     if dist:

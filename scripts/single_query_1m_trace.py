@@ -13,7 +13,7 @@ from shazam_amd import _ffi  # noqa: E402
 songs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ctx = _ffi.Context(0)
-tbl, build, _bufs = bench_db.build_table(ctx, songs, 30.0, 1000, finalize_every=100000)
+tbl, build, _bufs = bench_db.build_table(ctx, songs, 30.0, 1000, finalize_every=50000)
 n, qn = 30 * 44100, 10 * 44100
 rng = np.random.default_rng(3)
 lat = []

@@ -1108,8 +1108,9 @@ __device__ __forceinline__ uint32_t vt_query_of_tile(const vt_plan& pl, uint32_t
 // tile_start[g], g = 0 .. ntiles: the first tile of a query starts at the query's first vote, the others at the first
 // group border at or behind their nominal start (binary search: the votes are ordered by the bits >= g_lo)
 __global__ void vt_bounds_kernel(const uint32_t* __restrict__ k, vt_plan pl, uint32_t* __restrict__ tile_start,
-                                 uint32_t* __restrict__ n_heavy) {
+                                 uint32_t* __restrict__ n_heavy, unsigned long long* __restrict__ qbar) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, nt = pl.tb[pl.nq];
+  if (qbar && g <= VT_MAXQ) qbar[g] = 0ull;          // the queries' bars start at nothing (vt_stream2_kernel)
   if (g > nt) return;
   if (g == nt) { tile_start[g] = pl.qv[pl.nq]; *n_heavy = 0; return; }
   const uint32_t i = vt_query_of_tile(pl, g), l = g - pl.tb[i];
@@ -2052,6 +2053,8 @@ static void vt_make_plan(const uint64_t* counts, uint32_t nqp, const m_bits& mbp
   for (uint32_t i = 0; i < nqp; ++i) all_votes += counts[i];
   uint32_t chunk = VW_CHUNK;
   while (chunk < 16384u && all_votes / (2ull * chunk) >= 13312ull) chunk *= 2;
+  // (one query of 8.9 M votes, fewer tiles than wave slots: 1,024 votes a tile 0.379 ms, 2,048: 0.354, 4,096: 0.349 -- smaller tiles
+  // do not shorten the pass, every tile pays its start)
   if (chunk_env) chunk = chunk_env;
   pl.tile = chunk;
   static const uint32_t flush_env = [] { const char* e = getenv("SHZ_VW_FLUSH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : 0u; }();
@@ -2095,12 +2098,19 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
   uint32_t* n_heavy = tile_start + nt + 1;
   uint2* heavy = (uint2*)(tile_start + ((nt + 2 + 1) & ~1u));   // 8-byte aligned
   uint32_t* heavy_q = (uint32_t*)(heavy + hcap);
-  hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)nt + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start, n_heavy);
+  static const int vt_fast = [] { const char* e = getenv("SHZ_VT_FAST"); return e ? atoi(e) : 1; }();   // 0: the fold of round 3 (A/B)
+  static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
+  unsigned long long* d_qbar = nullptr;   // the bar of every query of the pass (its tiles' n-th candidates, atomicMax); zeroed by vt_bounds_kernel
+  if (vt_fast && !no_qr) {
+    void* p;
+    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT6, 8ull * (VT_MAXQ + 1), &p));
+    d_qbar = (unsigned long long*)p;
+  }
+  hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)std::max<uint32_t>(nt, VT_MAXQ) + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start,
+                     n_heavy, d_qbar);
   // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
   const int slb_ = pl.g_lo - 1 - mbp.dbits;
   const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(max_sid, 1u));
-  static const bool no_qr = [] { const char* e = getenv("SHZ_VT_NO_REJECT"); return e && atoi(e) != 0; }();
-  static const int vt_fast = [] { const char* e = getenv("SHZ_VT_FAST"); return e ? atoi(e) : 1; }();   // 0: the fold of round 3 (A/B)
   const bool few_songs = (double)(1u << slb_) + (double)pl.flush / per_song <= 40.0;
   const uint32_t plim = vt_probe_limit_1 ? vt_probe_limit_1 : (uint32_t)VW_S1;
   static const bool vt_stats = [] { const char* e = getenv("SHZ_VT_STATS"); return e && atoi(e) != 0; }();
@@ -2110,13 +2120,6 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC3, 64, &p));
     d_stats = (unsigned long long*)p;
     SHZ_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, ctx->stream));
-  }
-  unsigned long long* d_qbar = nullptr;   // the bar of every query of the pass (its tiles' n-th candidates, atomicMax)
-  if (vt_fast && !no_qr) {
-    void* p;
-    SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT6, 8ull * (VT_MAXQ + 1), &p));
-    d_qbar = (unsigned long long*)p;
-    SHZ_HIP(ctx, hipMemsetAsync(d_qbar, 0, 8ull * (VT_MAXQ + 1), ctx->stream));
   }
   if (vt_fast && !no_qr) {
     if (few_songs)
