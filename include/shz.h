@@ -189,6 +189,15 @@ int32_t shz_fingerprint_batch(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
  * bytes that went that way, seconds the upload thread spent copying, seconds the passes waited for a chunk. */
 int32_t shz_upload_stats(shz_ctx* ctx, uint64_t* chunks, uint64_t* bytes, double* copy_s, double* wait_s);
 
+/* The window of mlab.specgram as fingerprint() calls it (__init__.py:232-237): NFFT = wsize = 4096 is what the STFT kernel is
+ * built for (its radix plan, LDS layout and the 2049-bin peak stage); `noverlap = int(wsize * wratio)` is free: every
+ * extraction call of the context then cuts frames x[k hop : k hop + 4096], hop = 4096 - noverlap (mlab:307-308), and a clip
+ * of n >= 4096 samples has (n - 4096) / hop + 1 frames (shz_frame_count_hop; shz_frame_count is the default hop 2048).
+ * noverlap >= 4096: SHZ_E_INVALID (mlab raises ValueError, mlab:242).  Other wsize: not implemented -- the Python layer raises
+ * NotImplementedError, there is no CPU fallback. */
+int32_t shz_set_overlap(shz_ctx* ctx, uint32_t noverlap);
+uint32_t shz_frame_count_hop(uint64_t n_samples, uint32_t hop);
+
 /* Staging precision of shz_peaks / shz_fingerprint_batch.  Default (0): the power spectrogram is staged in fp32 and
  * the cells fp32 cannot decide (shared window maxima, threshold within 1e-7) are re-derived in fp64; results are
  * those of the fp64 path bit for bit.  1: stage fp64 and decide everything in the peak kernel (twice the HBM traffic;

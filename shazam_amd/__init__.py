@@ -19,7 +19,7 @@ from time import time
 import numpy as np
 
 from . import _ffi
-from ._ffi import Context, ShzError, Table  # noqa: F401
+from ._ffi import HOP, NFFT, Context, ShzError, Table  # noqa: F401
 
 # reference constants (__init__.py:41-51, recognizer.py:21-38,40-58,68)
 RATE = 44100
@@ -140,18 +140,32 @@ def _as_pcm(channel_samples) -> np.ndarray:
     raise NotImplementedError(f"the HIP path takes 16-bit integer PCM, got dtype {x.dtype}")
 
 
-def _check_window(wsize, wratio):
-    if int(int(wsize) * float(wratio)) >= int(wsize):   # what mlab.specgram raises for this call (mlab:242)
+def _check_window(wsize, wratio) -> int:
+    """noverlap = int(wsize * wratio) as fingerprint() hands it to mlab.specgram (__init__.py:232-237)."""
+    noverlap = int(int(wsize) * float(wratio))
+    if noverlap >= int(wsize):   # what mlab.specgram raises for this call (mlab:242)
         raise ValueError("noverlap must be less than NFFT")
-    if int(wsize) != DEFAULT_WINDOW_SIZE or float(wratio) != DEFAULT_OVERLAP_RATIO:
-        raise NotImplementedError("the HIP STFT kernel is built for wsize=4096, wratio=0.5 (the reference's "
-                                  "only configuration); other windows are not implemented and there is no CPU fallback")
+    if noverlap < 0:
+        raise ValueError("wratio must not be negative")
+    if int(wsize) != DEFAULT_WINDOW_SIZE:
+        raise NotImplementedError("the HIP STFT kernel is built for wsize=4096 (the reference's only window size: its radix plan, "
+                                  "LDS layout and 2049-bin peak stage); any wratio is taken, other window sizes are not implemented "
+                                  "and there is no CPU fallback")
+    return noverlap
 
 
-def fingerprint_batch(clips, Fs: int = RATE, fan_value: int = DEFAULT_FAN_VALUE, amp_min=DEFAULT_AMP_MIN, ctx: Context = None):
+def fingerprint_batch(clips, Fs: int = RATE, fan_value: int = DEFAULT_FAN_VALUE, amp_min=DEFAULT_AMP_MIN, ctx: Context = None,
+                      wratio: float = DEFAULT_OVERLAP_RATIO):
     """Batched fingerprint(): clips = list of 1-D int16 arrays (or a 2-D array).
     Returns (key32, t1, hash_off): hashes of clip c are [hash_off[c], hash_off[c+1])."""
     ctx = ctx or get_context()
+    noverlap = _check_window(DEFAULT_WINDOW_SIZE, wratio)
+    if NFFT - noverlap != getattr(ctx, "hop", HOP):
+        ctx.set_overlap(noverlap)
+        try:
+            return fingerprint_batch(clips, Fs, fan_value, amp_min, ctx, wratio)
+        finally:
+            ctx.set_overlap(NFFT - HOP)
     arrs = [_as_pcm(c) for c in clips]
     off = np.zeros(len(arrs) + 1, np.uint64)
     if arrs:
@@ -169,7 +183,7 @@ def fingerprint(channel_samples, Fs: int = RATE, wsize: int = DEFAULT_WINDOW_SIZ
     Returns list[(hex20, t1)] in the reference's generation order."""
     _check_window(wsize, wratio)
     ctx = get_context()
-    k, t1, _ = fingerprint_batch([channel_samples], Fs, fan_value, amp_min, ctx)
+    k, t1, _ = fingerprint_batch([channel_samples], Fs, fan_value, amp_min, ctx, wratio)
     return list(zip(hex_of_keys(ctx, k), t1.tolist()))
 
 

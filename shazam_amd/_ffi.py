@@ -49,6 +49,8 @@ SIGNATURES = {
     "shz_sort_keys32": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
     "shz_sort_keys32_seg": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
+    "shz_frame_count_hop": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+    "shz_set_overlap": (C.c_int32, [vp, C.c_uint32]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -372,6 +374,14 @@ class Context:
         self.check(lib().shz_upload_stats(self.h, C.byref(c), C.byref(b), C.byref(cs), C.byref(ws)))
         return {"chunks": c.value, "bytes": b.value, "copy_s": cs.value, "wait_s": ws.value}
 
+    def set_overlap(self, noverlap: int):
+        """noverlap of mlab.specgram for every later extraction call of this context (default 2048 = int(4096 * 0.5))."""
+        self.check(lib().shz_set_overlap(self.h, int(noverlap)))
+        self.hop = NFFT - int(noverlap)
+
+    def frames_of(self, n_samples: int) -> int:
+        return int(lib().shz_frame_count_hop(int(n_samples), int(getattr(self, "hop", HOP))))
+
     def set_stage_f64(self, enabled: bool):
         """fp64 staging of the power spectrogram (exact ties decided in the peak kernel) instead of fp32 + verify."""
         self.check(lib().shz_set_stage_f64(self.h, 1 if enabled else 0))
@@ -384,7 +394,7 @@ class Context:
 
     def stft_db(self, pcm, clip_off, fs=44100, pcm_device=False, power=False):
         co, nc = self._clip_off(clip_off)
-        frames = [int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc)]
+        frames = [self.frames_of(int(co[i + 1] - co[i])) for i in range(nc)]
         out = np.empty(sum(frames) * NBINS, np.float64)
         cnt = C.c_uint64()
         self.check(lib().shz_stft_db(self.h, ptr(pcm), co.ctypes.data_as(u64p), nc, fs,
@@ -398,7 +408,7 @@ class Context:
 
     def peaks(self, pcm, clip_off, fs=44100, amp_min=10.0, pcm_device=False):
         co, nc = self._clip_off(clip_off)
-        total_frames = sum(int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc))
+        total_frames = sum(self.frames_of(int(co[i + 1] - co[i])) for i in range(nc))
         cap = max(1024, total_frames * 16)
         flags = PCM_DEVICE if pcm_device else 0
         while True:
@@ -453,7 +463,7 @@ class Context:
                                                    flags | OUT_DEVICE, ptr(out_key), ptr(out_t1), ho.ctypes.data_as(u64p), cap,
                                                    C.byref(cnt)))
             return None, None, ho, int(cnt.value)
-        total_frames = sum(int(lib().shz_frame_count(int(co[i + 1] - co[i]))) for i in range(nc))
+        total_frames = sum(self.frames_of(int(co[i + 1] - co[i])) for i in range(nc))
         cap = max(1024, total_frames * 40)
         while True:
             k, t1 = np.empty(cap, np.uint32), np.empty(cap, np.uint32)

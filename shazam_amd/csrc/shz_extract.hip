@@ -81,6 +81,7 @@ struct stft_args {
   const cplx* tw;              // [1025] W4096^k
   double scale;                // 0.25 / (Fs * sum(w^2))
   uint32_t opt;                // experiment switches (SHZ_STFT_OPT): 1 = no rotation of the special wave, 2 = one frame loop for all waves
+  uint32_t hop;                // new samples per frame = NFFT - noverlap (mlab:307-308); 2,048 unless shz_set_overlap says otherwise
 };
 
 // The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
@@ -136,7 +137,7 @@ __device__ __forceinline__ void dft8f(cplx* v) {
 // (lo16 = x[2n], hi16 = x[2n+1], n = j + 256 t)
 __device__ __forceinline__ void stft_load_frame(const stft_args& a, uint32_t lo, uint32_t g, int j, int (&pw)[8]) {
   const uint64_t clen = a.clip_len[lo];
-  const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * SHZ_HOP;
+  const uint64_t s_in_clip = (uint64_t)(g - a.clip_foff[lo]) * a.hop;
   const int16_t* src = a.pcm + a.clip_soff[lo] + s_in_clip;
   const uint64_t avail = clen > s_in_clip ? clen - s_in_clip : 0;  // samples readable from src
   if (avail >= SHZ_NFFT && (((uintptr_t)src) & 3) == 0) {
@@ -1073,6 +1074,12 @@ extern "C" int32_t shz_db_values(const double* power, uint64_t n, double* out_db
   return SHZ_OK;
 }
 
+// frames mlab.specgram cuts n samples into with `hop` = NFFT - noverlap new samples a frame (mlab:268-271, 307-308)
+static inline uint32_t frames_hop(uint64_t n, uint32_t hop) {
+  if (n < SHZ_NFFT) return 1;
+  return (uint32_t)std::min<uint64_t>((n - SHZ_NFFT) / hop + 1, 0xFFFFFFFFull);
+}
+extern "C" uint32_t shz_frame_count_hop(uint64_t n, uint32_t hop) { return hop >= 1 && hop <= SHZ_NFFT ? frames_hop(n, hop) : 0; }
 extern "C" uint32_t shz_frame_count(uint64_t n) {
   if (n < SHZ_NFFT) return 1;
   return (uint32_t)((n - SHZ_NFFT) / SHZ_HOP + 1);
@@ -1113,7 +1120,7 @@ static int32_t plan_sub_batches(shz_ctx* ctx, const uint64_t* clip_off, uint32_t
   sub_batch cur{0, 0, 0};
   for (uint32_t c = 0; c < n_clips; ++c) {
     if (clip_off[c + 1] < clip_off[c]) SHZ_FAIL(ctx, SHZ_E_INVALID, "clip_off must be non-decreasing (clip %u)", c);
-    uint64_t f = shz_frame_count(clip_off[c + 1] - clip_off[c]);
+    uint64_t f = frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop);
     if (f > max_frames)
       SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "clip %u has %llu frames; at most %llu fit the workspace limit", c,
                (unsigned long long)f, (unsigned long long)max_frames);
@@ -1156,7 +1163,7 @@ static int32_t upload_meta(shz_ctx* ctx, const uint64_t* clip_off, const sub_bat
   // one blob: soff[nc] | len[nc] | foff[nc+1] (u32, padded to 8) | segs
   const uint64_t foff_words = (nc + 2) / 2;  // u64 words holding nc+1 u32
   for (uint32_t i = 0; i < nc; ++i) {
-    const uint32_t f = shz_frame_count(clip_off[sb.c0 + i + 1] - clip_off[sb.c0 + i]);
+    const uint32_t f = frames_hop(clip_off[sb.c0 + i + 1] - clip_off[sb.c0 + i], ctx->hop);
     sd.foff[i + 1] = sd.foff[i] + f;
     for (uint32_t t0 = 0; t0 < f; t0 += seg_len)
       segs.push_back(peak_seg{sd.foff[i], f, t0, std::min(t0 + seg_len, f)});
@@ -1209,6 +1216,7 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.total_frames = frames;
   a.out = d_out;
   a.window = ctx->d_window;
+  a.hop = ctx->hop;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
   a.frames_per_wg = 0;
@@ -1362,7 +1370,7 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
                                uint32_t fs, uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* count) {
   SHZ_TRY(check_common(ctx, pcm, clip_off, n_clips, fs));
   uint64_t need = 0;
-  for (uint32_t c = 0; c < n_clips; ++c) need += (uint64_t)shz_frame_count(clip_off[c + 1] - clip_off[c]) * SHZ_NBINS;
+  for (uint32_t c = 0; c < n_clips; ++c) need += (uint64_t)frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop) * SHZ_NBINS;
   if (count) *count = need;
   if (need > cap_doubles || (need && !out_db)) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_stft_db: need %llu doubles", (unsigned long long)need);
   std::vector<sub_batch> subs;
@@ -1448,7 +1456,7 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
   // with many waves, and beside the STFT it gets one wave per SIMD (2.1 -> 4-6 ms while the STFT goes 4.4 -> 4.7).
   static const int ov_split = [] { const char* e = getenv("SHZ_OVERLAP_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
   uint64_t frames_total = 0;
-  for (uint32_t c = 0; c < n_clips; ++c) frames_total += shz_frame_count(clip_off[c + 1] - clip_off[c]);
+  for (uint32_t c = 0; c < n_clips; ++c) frames_total += frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop);
   const bool want_overlap = xp.f32 && ov_split >= 2 && frames_total >= 65536;
   std::vector<sub_batch> subs;
   SHZ_TRY(plan_sub_batches(ctx, clip_off, n_clips, xp.f32 ? (uint64_t)P32_STRIDE * 4 : (uint64_t)DB_STRIDE * 8, subs,
@@ -1813,7 +1821,7 @@ static int32_t splice_f64_clips(shz_ctx* ctx, const int16_t* pcm, const uint64_t
   for (size_t fi = 0; fi < flagged.size(); ++fi) {
     const uint32_t c = flagged[fi];
     redo& r = R[fi];
-    const uint64_t frames_c = shz_frame_count(clip_off[c + 1] - clip_off[c]);
+    const uint64_t frames_c = frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop);
     uint64_t cap_c = frames_c * 64 * (want_hashes ? (fan > 1 ? fan - 1 : 1) : 1) + 4096;
     uint64_t o2[2] = {0, 0};
     if (out_dev) {
@@ -1931,7 +1939,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
   if (count) *count = 0;
   if (n_clips == 0) return SHZ_OK;
   uint64_t frames = 0;
-  for (uint32_t c = 0; c < n_clips; ++c) frames += shz_frame_count(clip_off[c + 1] - clip_off[c]);
+  for (uint32_t c = 0; c < n_clips; ++c) frames += frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop);
   static const bool force_f64 = [] { const char* e = getenv("SHZ_STAGE_F64"); return e && atoi(e) != 0; }();
   xparams xp;
   // fp32 staging needs the threshold to be a positive normal fp32 power well inside the range; amp_min < 0 also needs
@@ -1952,7 +1960,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
   if (dual_on && n_clips >= 2 && frames >= 131072) {
     uint32_t hc = 1;
     for (uint64_t f = 0; hc < n_clips - 1; ++hc) {
-      f += shz_frame_count(clip_off[hc] - clip_off[hc - 1]);
+      f += frames_hop(clip_off[hc] - clip_off[hc - 1], ctx->hop);
       if (2 * f >= frames) break;
     }
     if (!ctx->twin) {
@@ -1968,7 +1976,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     xparams xa = xp, xb = xp;
     xa.persistent_stft = xb.persistent_stft = true;
     uint64_t fb = 0;
-    for (uint32_t c = hc; c < n_clips; ++c) fb += shz_frame_count(clip_off[c + 1] - clip_off[c]);
+    for (uint32_t c = hc; c < n_clips; ++c) fb += frames_hop(clip_off[c + 1] - clip_off[c], ctx->hop);
     xa.stage_cap = std::min<uint64_t>(cap, (frames - fb) * per_frame_out + 4096);
     xb.stage_cap = fb * per_frame_out + 4096;
     pass_tail ta, tb;
@@ -2196,6 +2204,14 @@ extern "C" int32_t shz_upload_stats(shz_ctx* ctx, uint64_t* chunks, uint64_t* by
   if (bytes) *bytes = ctx->st_up_bytes;
   if (copy_s) *copy_s = ctx->st_up_copy_s;
   if (wait_s) *wait_s = ctx->st_up_wait_s;
+  return SHZ_OK;
+}
+
+extern "C" int32_t shz_set_overlap(shz_ctx* ctx, uint32_t noverlap) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (noverlap >= SHZ_NFFT) SHZ_FAIL(ctx, SHZ_E_INVALID, "noverlap must be less than NFFT (%u >= %d)", noverlap, SHZ_NFFT);   // mlab:242
+  ctx->hop = SHZ_NFFT - noverlap;
+  if (ctx->twin) ctx->twin->hop = ctx->hop;
   return SHZ_OK;
 }
 

@@ -98,6 +98,7 @@ struct shz_ctx {
   int16_t* d_sine_lut = nullptr;
   double m_votes_per_hash = 0.0;   // votes per query hash of the last match sub-batch: sizes the next one before it is tried
   double win_sumsq = 0.0;
+  uint32_t hop = SHZ_HOP;          // new samples per frame: NFFT - noverlap (shz_set_overlap; the reference's wratio)
   // timers / profiling
   hipEvent_t tev[16][2];
   bool tev_init = false;

@@ -154,10 +154,32 @@ def tie_cases(ref):
     np.savez_compressed(os.path.join(HERE, "tie_cases.npz"), **tie)
 
 
+VARIANTS = {"amp0": dict(amp_min=0), "amp25": dict(amp_min=25), "ampneg5": dict(amp_min=-5), "amp33p3": dict(amp_min=33.3),
+            "fan2": dict(fan_value=2), "fan10": dict(fan_value=10), "fan1": dict(fan_value=1),
+            "fs8000": dict(Fs=8000), "fs48000": dict(Fs=48000),
+            # wratio: noverlap = int(4096 * wratio), hop = 4096 - noverlap (round 4): 1024, 3072, 4096 and the odd 411
+            "wr075": dict(wratio=0.75), "wr025": dict(wratio=0.25), "wr0": dict(wratio=0.0), "wr08999": dict(wratio=0.8999)}
+
+
+def param_variants(ref):
+    """(iii-b) non-default parameters of fingerprint(): amp_min, fan_value, Fs, wratio"""
+    var = {}
+    xv = synth.synth_clip(1234, 7, 2048 * 90 + 5, 4000, 1500)
+    var["pcm_params"] = np.array([1234, 7, 2048 * 90 + 5, 4000, 1500], np.int64)
+    for tag, kw in VARIANTS.items():
+        hs = ref.fingerprint(xv, **kw)
+        var[f"{tag}_hash_hex"] = np.array([h for h, _ in hs], dtype="S20")
+        var[f"{tag}_hash_t1"] = np.array([int(o) for _, o in hs], np.int64)
+        print("variant", tag, len(hs), "hashes")
+    np.savez_compressed(os.path.join(HERE, "param_variants.npz"), **var)
+
+
 def main():
     ref = load_reference_extraction()
     if "--only-ties" in sys.argv:
         return tie_cases(ref)
+    if "--only-variants" in sys.argv:
+        return param_variants(ref)
     meta = {"numpy": np.__version__}
     import matplotlib
     import scipy
@@ -209,18 +231,7 @@ def main():
         print(name, int(r["n_frames"]), "frames", len(r["peaks_f"]), "peaks", len(r["hash_hex"]), "hashes")
     np.savez_compressed(os.path.join(HERE, "edge_cases.npz"), **edge)
 
-    # (iii-b) non-default parameters of fingerprint(): amp_min, fan_value, Fs ------------------------------
-    var = {}
-    xv = synth.synth_clip(1234, 7, 2048 * 90 + 5, 4000, 1500)
-    var["pcm_params"] = np.array([1234, 7, 2048 * 90 + 5, 4000, 1500], np.int64)
-    for tag, kw in {"amp0": dict(amp_min=0), "amp25": dict(amp_min=25), "ampneg5": dict(amp_min=-5), "amp33p3": dict(amp_min=33.3),
-                    "fan2": dict(fan_value=2), "fan10": dict(fan_value=10), "fan1": dict(fan_value=1),
-                    "fs8000": dict(Fs=8000), "fs48000": dict(Fs=48000)}.items():
-        hs = ref.fingerprint(xv, **kw)
-        var[f"{tag}_hash_hex"] = np.array([h for h, _ in hs], dtype="S20")
-        var[f"{tag}_hash_t1"] = np.array([int(o) for _, o in hs], np.int64)
-        print("variant", tag, len(hs), "hashes")
-    np.savez_compressed(os.path.join(HERE, "param_variants.npz"), **var)
+    param_variants(ref)
 
     tie_cases(ref)
 

@@ -1,5 +1,6 @@
-"""Non-default fingerprint() parameters (amp_min, fan_value, Fs) against outputs of the reference
-(tests/golden/param_variants.npz): oracle on CPU, HIP path on the GPU."""
+"""Non-default fingerprint() parameters (amp_min, fan_value, Fs, wratio) against outputs of the reference
+(tests/golden/param_variants.npz): oracle on CPU, HIP path on the GPU.  wsize other than 4096 is refused (documented:
+INTEGRATION.md 4)."""
 import os
 
 import numpy as np
@@ -7,7 +8,8 @@ import pytest
 
 VARIANTS = {"amp0": dict(amp_min=0), "amp25": dict(amp_min=25), "ampneg5": dict(amp_min=-5), "amp33p3": dict(amp_min=33.3),
             "fan2": dict(fan_value=2), "fan10": dict(fan_value=10), "fan1": dict(fan_value=1),
-            "fs8000": dict(Fs=8000), "fs48000": dict(Fs=48000)}
+            "fs8000": dict(Fs=8000), "fs48000": dict(Fs=48000),
+            "wr075": dict(wratio=0.75), "wr025": dict(wratio=0.25), "wr0": dict(wratio=0.0), "wr08999": dict(wratio=0.8999)}
 
 
 def _load(golden_dir):
@@ -34,5 +36,8 @@ def test_gpu_variants(golden_dir):
         hs = S.fingerprint(x, **kw)
         assert [h.encode() for h, _ in hs] == list(g[f"{tag}_hash_hex"]), tag
         assert [o for _, o in hs] == list(g[f"{tag}_hash_t1"]), tag
+    assert S.fingerprint(x) == S.fingerprint(x, wratio=0.5)      # the context's overlap is back at its default after a variant
     with pytest.raises(NotImplementedError):
-        S.fingerprint(x, wratio=0.75)
+        S.fingerprint(x, wsize=2048)
+    with pytest.raises(ValueError):
+        S.fingerprint(x, wratio=1.0)                             # mlab: noverlap must be less than NFFT
