@@ -1905,7 +1905,46 @@ static int32_t splice_f64_clips(shz_ctx* ctx, const int16_t* pcm, const uint64_t
     *total = new_total;
     return SHZ_OK;
   }
-  // host arrays: from the back, so that the offsets in front of a clip stay what they are
+  // host arrays.  Spliced in place from the back (the offsets in front of a clip stay what they are) -- unless an
+  // INTERMEDIATE total would outgrow the caller's arrays although the final one fits (a late clip grows by k, an early one
+  // shrinks by k: the first move writes total + k entries): then the result is put together in scratch, front to
+  // back, and copied over once.
+  {
+    uint64_t running = *total, peak = *total;
+    for (size_t fi = flagged.size(); fi-- > 0;) {
+      const uint32_t c = flagged[fi];
+      running = running - (offs[c + 1] - offs[c]) + R[fi].cnt;
+      peak = std::max(peak, running);
+    }
+    if (peak > cap) {
+      std::vector<char> na(new_total * b_a), nb(new_total * 4);
+      uint64_t src = 0, dst = 0;
+      for (size_t fi = 0; fi < flagged.size(); ++fi) {
+        const uint32_t c = flagged[fi];
+        const redo& r = R[fi];
+        const uint64_t keep = offs[c] - src;
+        if (keep) { memcpy(na.data() + dst * b_a, (char*)A + src * b_a, keep * b_a); memcpy(nb.data() + dst * 4, (char*)B + src * 4, keep * 4); }
+        dst += keep;
+        if (r.cnt) {
+          memcpy(na.data() + dst * b_a, want_hashes ? (const void*)r.a32.data() : (const void*)r.a16.data(), r.cnt * b_a);
+          memcpy(nb.data() + dst * 4, r.b.data(), r.cnt * 4);
+        }
+        dst += r.cnt;
+        src = offs[c + 1];
+      }
+      const uint64_t rest = *total - src;
+      if (rest) { memcpy(na.data() + dst * b_a, (char*)A + src * b_a, rest * b_a); memcpy(nb.data() + dst * 4, (char*)B + src * 4, rest * 4); }
+      dst += rest;
+      if (dst) { memcpy(A, na.data(), dst * b_a); memcpy(B, nb.data(), dst * 4); }
+      for (size_t fi = flagged.size(); fi-- > 0;) {
+        const uint32_t c = flagged[fi];
+        const uint64_t old = offs[c + 1] - offs[c];
+        for (uint32_t i = c + 1; i <= n_clips; ++i) offs[i] = offs[i] - old + R[fi].cnt;
+      }
+      *total = new_total;
+      return SHZ_OK;
+    }
+  }
   for (size_t fi = flagged.size(); fi-- > 0;) {
     const uint32_t c = flagged[fi];
     const redo& r = R[fi];

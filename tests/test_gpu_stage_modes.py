@@ -155,3 +155,38 @@ def test_one_tied_clip_among_many_is_redone_alone(env):
         assert np.array_equal(kb.download(np.uint32, cnt), a[0]) and np.array_equal(tb.download(np.uint32, cnt), a[1])
         for buf in (d_pcm, kb, tb):
             buf.free()
+
+
+def test_several_redone_clips_with_exactly_the_final_capacity(env):
+    """the host splice of re-run clips moved entries in place from the back, and an intermediate total could
+    outgrow arrays that hold exactly the final count (a late clip grows, an early one shrinks).  Several tied clips among
+    noise clips, host outputs, capacity == what the first call reported: the same arrays as with room to spare."""
+    S, ctx, synth = env
+    from shazam_amd import _ffi
+    import ctypes as C
+    ties = synth.tie_inputs()
+    click = np.zeros(2048 * 60, np.int16)
+    click[1024::2048] = 20000
+    xs = [synth.synth_clip(17, c, 2048 * (40 + 5 * c), 0, 8000) for c in range(9)]
+    xs[1], xs[4], xs[7] = ties["two_tone_10s"][:2048 * 80], click, ties["sine_1k_10s"][:2048 * 70]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.uint64)
+    x = np.concatenate(xs)
+    s0 = ctx.extract_stats()
+    k_ref, t_ref, ho_ref, n_ref = ctx.fingerprint_batch(x, off)      # generous capacity
+    assert ctx.extract_stats()["f64_clips"] - s0["f64_clips"] >= 2   # several clips were re-run and spliced
+    L = _ffi.lib()
+    for cap in (n_ref, n_ref + 1):
+        k, t1 = np.full(cap + 64, 0xDEADBEEF, np.uint32), np.full(cap + 64, 0xDEADBEEF, np.uint32)   # 64 guard entries behind `cap`
+        ho, cnt = np.zeros(len(xs) + 1, np.uint64), C.c_uint64()
+        rc = L.shz_fingerprint_batch(ctx.h, _ffi.ptr(x), off.ctypes.data_as(_ffi.u64p), len(xs), 44100, 10.0, 5, 0,
+                                     _ffi.ptr(k), _ffi.ptr(t1), ho.ctypes.data_as(_ffi.u64p), cap, C.byref(cnt))
+        assert rc == 0 and cnt.value == n_ref
+        assert np.array_equal(k[:n_ref], k_ref) and np.array_equal(t1[:n_ref], t_ref) and np.array_equal(ho, ho_ref)
+        assert np.all(k[cap:] == 0xDEADBEEF) and np.all(t1[cap:] == 0xDEADBEEF)       # nothing written past the capacity
+    # one entry too few: SHZ_E_CAPACITY and the count to provide, nothing past the capacity
+    k, t1 = np.full(n_ref + 63, 0xDEADBEEF, np.uint32), np.full(n_ref + 63, 0xDEADBEEF, np.uint32)
+    ho, cnt = np.zeros(len(xs) + 1, np.uint64), C.c_uint64()
+    rc = L.shz_fingerprint_batch(ctx.h, _ffi.ptr(x), off.ctypes.data_as(_ffi.u64p), len(xs), 44100, 10.0, 5, 0,
+                                 _ffi.ptr(k), _ffi.ptr(t1), ho.ctypes.data_as(_ffi.u64p), n_ref - 1, C.byref(cnt))
+    assert rc == _ffi.E_CAPACITY and cnt.value >= n_ref
+    assert np.all(k[n_ref - 1:] == 0xDEADBEEF) and np.all(t1[n_ref - 1:] == 0xDEADBEEF)
