@@ -330,3 +330,34 @@ def test_key_sharded_table_over_thread_ranks():
         assert np.array_equal(sum(o[1][name].astype(np.uint64) for o in outs), want[name].astype(np.uint64)), name
     ref.close()
     ref_ctx.close()
+
+
+def test_pipelined_build_over_a_one_rank_rccl_communicator():
+    """The exchange rounds over REAL RCCL (one rank: all a one-GPU lease allows -- ncclCommInitRank refuses two ranks on one
+    device): ncclAllGather of the round's block on the communicator's exchange stream, the event that orders that stream
+    behind the seal, the list exchange's early return, rounds counted; the table equals the plain build's."""
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    rng = np.random.default_rng(12)
+    blocks = [_rows(rng, 900, tr + 1, tr + 2) for tr in range(60)]
+    want = np.unique(np.concatenate([np.stack(b, 1) for b in blocks]).astype(np.uint64), axis=0)
+    ctx = _ffi.Context(0)
+    try:
+        comm = _ffi.Comm(ctx, _ffi.comm_unique_id(), 0, 1)
+    except _ffi.ShzError as e:
+        pytest.skip(f"librccl not usable here: {e}")
+    tbl = S.Table(ctx)
+    tbl.set_segment_rows(20000)
+    tbl.reserve(0, 0, gather=True)
+    for i, b in enumerate(blocks):
+        tbl.insert(*b)
+        if i % 15 == 14:
+            tbl.exchange_run(comm)
+    assert tbl.exchange_stats()["rounds"] == 4 and tbl.exchange_stats()["runs_held"] == 4
+    recv = tbl.allgather(comm)
+    k, s, o = tbl.export()
+    rows = np.stack([k, s, o], 1).astype(np.uint64)
+    assert recv == 0 and np.array_equal(rows, want) and tbl.segments() >= 2
+    tbl.close()
+    comm.close()
+    ctx.close()
