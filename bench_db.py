@@ -82,6 +82,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
             if not held:
                 tbl.reserve(rows_hint, batch_hint)
     t_reserve = time.perf_counter() - t_build0
+    t_mark = time.perf_counter()
     cap = chunk * frames * 24 + 1024
     kbuf, tbuf = ctx.alloc(cap * 4), ctx.alloc(cap * 4)
     overlap_synth = overlap_synth and songs > chunk
@@ -91,6 +92,9 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     n_rows_in = 0
     starts = list(range(0, songs, chunk))
     synth_tracks(ctx_s, corpus, 0, min(chunk, songs), n_samples, tone_amp, noise_amp, pcms[0])
+    ctx.sync()
+    t_setup = time.perf_counter() - t_mark   # buffers + the first chunk's synthesis
+    t_loop0 = time.perf_counter()
     for i, c0 in enumerate(starts):
         nc = min(chunk, songs - c0)
         pcm = pcms[i % len(pcms)]
@@ -116,6 +120,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
             t_fin += time.perf_counter() - t0
             if progress:
                 progress(c0 + nc)
+    t_loop = time.perf_counter() - t_loop0
     t0 = time.perf_counter()
     tbl.finalize()
     ctx.sync()
@@ -127,7 +132,7 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     if ctx_s is not ctx:
         ctx_s.close()
     stats = {"seconds_total": t_build, "reserve_s": t_reserve, "fingerprint_s": t_fp, "insert_s": t_ins, "finalize_s": t_fin,
-             "synth_wait_s": t_synth_wait, "synth_overlapped": bool(overlap_synth),
+             "synth_wait_s": t_synth_wait, "synth_overlapped": bool(overlap_synth), "setup_s": t_setup, "loop_s": t_loop,
              "rows_inserted": int(n_rows_in), "rows": int(rows), "songs_per_s": songs / t_build,
              "audio_s_per_s": songs * seconds / t_build, "segments": int(tbl.segments()) if shards == 1 else None,
              "key_range_segments": bool(shards == 1 and reserve and held),

@@ -1783,7 +1783,10 @@ static int32_t flush_runs(shz_table* t, bool final) {
   shz_ctx* ctx = t->ctx;
   uint64_t total = runs_rows(t);
   if (total == 0) { t->runs.clear(); return SHZ_OK; }
-  if (t->gx_stream) SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));   // every run has arrived
+  if (t->gx_stream) {   // every run has arrived; nothing of this table is on the communicator's stream any more (the table may outlive it)
+    SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));
+    t->gx_stream = nullptr;
+  }
   if (t->runs.size() > KW_MAXK) SHZ_TRY(collapse_runs(t, KW_MAXK));
   std::vector<const uint64_t*> ptr;
   for (const shz_run& r : t->runs) ptr.push_back(t->rbuf + r.off);
@@ -2226,6 +2229,7 @@ extern "C" int32_t shz_table_allgather(shz_table* t, shz_comm* c, uint64_t* byte
     const double w0 = now_s();
     SHZ_HIP(ctx, hipStreamSynchronize(t->gx_stream));
     t->gx_wait_s += now_s() - w0;
+    t->gx_stream = nullptr;
   }
   if (bytes_recv) *bytes_recv = t->gx_recv_bytes;
   t->bs_exchange = t->gx_xfer_s + t->gx_wait_s;   // host seconds inside exchange rounds (waiting for peers included), not link time
