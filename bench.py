@@ -454,6 +454,8 @@ def db_build_scaling(a, ctx, dist, comm, rank, world):
     db.table.reserve(rows_total, seal, gather=True, wait=True)
     t_reserve = time.perf_counter() - t0
     builder = ShardedBuilder(db, rank, world, comm, chunk_tracks=chunk, seal_rows=seal)
+    if comm is not None:
+        comm.warmup()   # RCCL connects two ranks on their first send / receive: not on this build's clock
     if dist:
         dist.barrier()
     ctx.sync()

@@ -358,6 +358,9 @@ int32_t shz_table_build_stats(shz_table* t, double* sort_s, double* exchange_s, 
 int32_t shz_table_phase_stats(shz_table* t, double* seconds, uint32_t cap, uint32_t* n, int32_t reset);
 const char* shz_table_phase_name(uint32_t i);
 int32_t shz_comm_barrier(shz_comm* c);
+/* Collective: one tiny exchange of each kind the gathered build uses, on the communicator's exchange stream.  RCCL connects
+ * two ranks when they first talk to each other; a build whose time matters calls this before its clock starts. */
+int32_t shz_comm_warmup(shz_comm* c);
 
 /* ---- key-sharded table (new; SURVEY.md 8f row 4: the table no longer fits one GPU) -------
  * Rows are partitioned by a hash of key32, so a DB row lives on exactly one shard and both quantities

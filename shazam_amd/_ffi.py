@@ -98,6 +98,7 @@ SIGNATURES = {
     "shz_table_phase_stats": (C.c_int32, [vp, C.POINTER(C.c_double), C.c_uint32, u32p, C.c_int32]),
     "shz_table_phase_name": (C.c_char_p, [C.c_uint32]),
     "shz_comm_barrier": (C.c_int32, [vp]),
+    "shz_comm_warmup": (C.c_int32, [vp]),
     "shz_shard_of_keys": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp]),
     "shz_table_keep_shard": (C.c_int32, [vp, C.c_uint32, C.c_uint32]),
     "shz_table_shard_exchange": (C.c_int32, [vp, vp, u64p]),
@@ -684,6 +685,10 @@ class Comm:
         ctx.check(lib().shz_comm_create_local(ctx.h, int(group_id), rank, nranks, C.byref(h)))
         self.h, self.rank, self.nranks = h, rank, nranks
         return self
+
+    def warmup(self):
+        """Collective: the connections between every pair of ranks exist afterwards (RCCL makes them on first use)."""
+        self.ctx.check(lib().shz_comm_warmup(self.h))
 
     def barrier(self):
         self.ctx.check(lib().shz_comm_barrier(self.h))

@@ -412,6 +412,32 @@ int32_t shz_comm_alltoallv_bytes(shz_comm* c, const void* d_send, const uint64_t
   return SHZ_OK;
 }
 
+// RCCL sets up the connection between two ranks when they first send to / receive from each other (hundreds of milliseconds
+// for a node's 28 pairs); a build that is timed calls this first: one 320-byte block all-gathered and one 256-byte buffer sent
+// to and received from every peer, on the exchange stream -- the two collectives the exchange rounds use.
+extern "C" int32_t shz_comm_warmup(shz_comm* c) {
+  if (!c) return SHZ_E_INVALID;
+  shz_ctx* ctx = c->ctx;
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s;
+  SHZ_TRY(shz_comm_exchange_stream(c, &s));
+  uint64_t blk[40] = {0}, all[40 * 64];
+  if (c->nranks > 64) SHZ_FAIL(ctx, SHZ_E_INVALID, "warm-up: more than 64 ranks");
+  SHZ_TRY(shz_comm_allgather_host(c, blk, all, sizeof(blk)));
+  void* d = nullptr;
+  SHZ_HIP(ctx, hipMalloc(&d, 256ull * (c->nranks + 1)));
+  std::vector<shz_xfer> send{shz_xfer{d, 256}};
+  std::vector<std::vector<shz_xfer>> recv(c->nranks);
+  for (int p = 0; p < c->nranks; ++p)
+    if (p != c->rank) recv[p].push_back(shz_xfer{(char*)d + 256ull * (p + 1), 256});
+  const int32_t rc = shz_comm_allgather_lists_on(c, s, send, recv);
+  const hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  SHZ_TRY(rc);
+  SHZ_HIP(ctx, e);
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_comm_barrier(shz_comm* c) {
   if (!c) return SHZ_E_INVALID;
   shz_ctx* ctx = c->ctx;

@@ -346,6 +346,7 @@ def test_pipelined_build_over_a_one_rank_rccl_communicator():
         comm = _ffi.Comm(ctx, _ffi.comm_unique_id(), 0, 1)
     except _ffi.ShzError as e:
         pytest.skip(f"librccl not usable here: {e}")
+    comm.warmup()
     tbl = S.Table(ctx)
     tbl.set_segment_rows(20000)
     tbl.reserve(0, 0, gather=True)
