@@ -1420,10 +1420,10 @@ struct xparams {
 
 #define UND_CAP (1u << 20)
 
-template <int NW, int OCC>
+template <int NW, int OCC, int AH = 1>
 static void launch_pick32(shz_ctx* ctx, const p32_args& pa, uint32_t n_segs) {
   const uint32_t per_xcd = (n_segs + 7) >> 3;   // segments per XCD; 8 * per_xcd * n_slabs workgroups, see the kernel's work map
-  hipLaunchKernelGGL((peak_pick32_kernel<NW, OCC>), dim3(8 * per_xcd * pa.n_slabs), dim3(64 * NW), 0, ctx->stream, pa);
+  hipLaunchKernelGGL((peak_pick32_kernel<NW, OCC, AH>), dim3(8 * per_xcd * pa.n_slabs), dim3(64 * NW), 0, ctx->stream, pa);
 }
 static int p32_occ() {
   static const int v = [] { const char* e = getenv("SHZ_PEAK_OCC"); const int x = e ? atoi(e) : 4; return x >= 3 && x <= 6 ? x : 4; }();
@@ -1604,6 +1604,10 @@ static int32_t extract_enqueue(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
         pa.ctl = d_ctl;
         pa.und_cap = UND_CAP;
         pa.frame_cnt = (uint32_t*)d_fcnt;
+        static const int p32_ahead = [] { const char* e = getenv("SHZ_PEAK_AHEAD"); return e ? atoi(e) : 1; }();
+        if (p32_ahead == 2 && mg.nw == 2) {   // experiment: 14 rows in flight per lane (3 or 4 waves per SIMD by SHZ_PEAK_OCC)
+          if (p32_occ() == 3) launch_pick32<2, 3, 2>(ctx, pa, sd.n_segs); else launch_pick32<2, 4, 2>(ctx, pa, sd.n_segs);
+        } else
         switch (mg.nw * 10 + p32_occ()) {
           case 13: launch_pick32<1, 3>(ctx, pa, sd.n_segs); break;
           case 14: launch_pick32<1, 4>(ctx, pa, sd.n_segs); break;
