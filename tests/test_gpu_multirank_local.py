@@ -362,3 +362,61 @@ def test_pipelined_build_over_a_one_rank_rccl_communicator():
     tbl.close()
     comm.close()
     ctx.close()
+
+
+def test_mixed_ingest_and_query_stream_over_thread_ranks():
+    """BASELINE configs[4] at N > 1, on one GPU: a gathered base table (runs sent on the way), then batches of NEW songs --
+    every rank stages its share, shz_table_allgather takes the column path into the live replicas (they hold rows), queries
+    run between the batches.  After every batch all ranks hold the same table, equal to a one-rank table that inserted the
+    same songs, and answer the queries alike (a query for a song ingested in the last batch finds it)."""
+    import shazam_amd as S
+    from shazam_amd import _ffi
+    from shazam_amd.ingest import shard_tracks
+    world, n_base, n_new, batches = 3, 90, 18, 3
+    rng = np.random.default_rng(404)
+    blocks = [_rows(rng, 700, tr + 1, tr + 2) for tr in range(n_base + n_new * batches)]
+    gid = 606060
+
+    def queries(upto):
+        tr = list(range(3, upto, 11)) + [upto - 1]           # incl. the newest song
+        qk = np.concatenate([blocks[t][0][:50] for t in tr])
+        qo = np.concatenate([blocks[t][2][:50] for t in tr])
+        return qk, qo, np.arange(0, len(qk) + 1, 50).astype(np.uint64), np.array(tr) + 1
+
+    def rank_fn(r):
+        ctx = _ffi.Context(0)
+        comm = _ffi.Comm.local(ctx, gid, r, world)
+        tbl = S.Table(ctx)
+        tbl.set_segment_rows(30000)
+        tbl.reserve(0, 0, gather=True)
+        lo, hi = shard_tracks(n_base, r, world)
+        for i, tr in enumerate(range(lo, hi)):
+            tbl.insert(*blocks[tr])
+            if i % 10 == 9:
+                tbl.exchange_run(comm)
+        tbl.allgather(comm)
+        out = []
+        for b in range(batches):
+            first = n_base + b * n_new
+            lo, hi = shard_tracks(n_new, r, world)
+            for tr in range(first + lo, first + hi):
+                tbl.insert(*blocks[tr])
+            tbl.allgather(comm)                               # the replicas hold rows: every rank takes the column path
+            qk, qo, qoff, want_sid = queries(first + n_new)
+            res = tbl.match(qk, qo, qoff, 2)
+            k, s, o = tbl.export()
+            rows = np.stack([k, s, o], 1).astype(np.uint64)
+            out.append((rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))], res, want_sid))
+        tbl.close(); comm.close(); ctx.close()
+        return out
+
+    outs = _run_ranks(world, rank_fn)
+    for b in range(batches):
+        upto = n_base + (b + 1) * n_new
+        want = np.unique(np.concatenate([np.stack(x, 1) for x in blocks[:upto]]).astype(np.uint64), axis=0)
+        for r in range(world):
+            rows, res, want_sid = outs[r][b]
+            assert len(rows) == len(want) and np.array_equal(rows, want), (b, r)
+            assert np.array_equal(res["sid"][:, 0], want_sid), (b, r)      # every queried song is found, the newest included
+            for name in res:
+                assert np.array_equal(res[name], outs[0][b][1][name]), (b, r, name)
