@@ -423,9 +423,11 @@ def db_build_scaling(a, ctx, dist, comm, rank, world):
         n_samples = int(round(sec * FS))
         frames = int(_ffi.lib().shz_frame_count(n_samples))
         rows_total = int(songs * frames * bench_db.ROWS_PER_FRAME_HINT)
-        # rows between two seals: <= 1e9 (a run is one radix sort), and with N > 1 a quarter of a rank's share -- what is still
-        # to travel when a rank's fingerprinting ends is its LAST run only (4 N <= 32 runs: one merge takes them)
-        seal = min(1_000_000_000, -(-rows_total // (world * (4 if world > 1 else 1))))
+        # rows between two seals: <= 1e9 (a run is one radix sort), and with N > 1 a fraction of a rank's share -- what is still
+        # to travel when a rank's fingerprinting ends is its LAST run only -- chosen so that the node has <= 16 runs in all
+        # (the merge's small tiles, shz_build.hip: KW_TILE_SMALL): 4 runs a rank at N <= 4, 2 at N = 8
+        per_rank = max(1, min(4, 16 // world)) if world > 1 else 1
+        seal = min(1_000_000_000, -(-rows_total // (world * per_rank)))
         # columns + arena of all runs + staging + one sort scratch + the extraction workspace and PCM of a chunk
         need = rows_total * 12 * 1.03 + (rows_total * 1.02 + seal * 1.2) * 8 + seal * 1.1 * 20 + 24e9
         return n_samples, frames, rows_total, seal, need

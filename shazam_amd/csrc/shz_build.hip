@@ -1060,9 +1060,15 @@ extern "C" int32_t shz_table_lookup(shz_table* t, const uint32_t* keys, uint64_t
 
 #define KW_MAXK 32             // runs one merge takes (more: the smallest are merged into one first)
 #define KW_THREADS 256
-#define KW_TILE 2048           // nominal rows of a tile = samples per tile x sample stride
-#define KW_TMAX (3 * KW_TILE)  // a tile holds fewer than (c + 2 k) M <= 3 c M rows (c samples per tile >= k runs, stride M)
-#define KW_PER (KW_TMAX / KW_THREADS)
+// Nominal rows of a tile = samples per tile x sample stride; a tile holds fewer than (c + 2 k) M <= 3 c M = 3 x nominal rows
+// (c samples per tile >= k runs, stride M): the LDS buffer of kw_tile_kernel<MODE, TILE> holds 3 TILE rows.  Two sizes
+// (round 4, 1.09e9 rows, plan + merge): 2,048 rows (48 KB of LDS, 3 workgroups a CU) k = 2 / 8 / 16: 9.7 / 18.2 / 25.1 ms;
+// 1,024 rows (24 KB, 6 workgroups: twice the waves to hide the merge rounds' dependent LDS reads): 6.8 / 14.5 / 21.5 ms
+// (512 rows: 7.0 / 15.3 / 23.4; 768: 7.0 / 15.4 / 22.9; 512 threads at 1,024: 7.5 / 17.0 / 25.4).  Beyond 16 runs the sample
+// stride of the small tile (1,024 / 32) doubles the samples to sort -- the plan's cost -- and the larger tile is kept.
+#define KW_TILE_SMALL 1024
+#define KW_TILE_LARGE 2048
+#define KW_TMAX (3 * KW_TILE_LARGE)   // the largest tile any instantiation holds (bounds of the flush's scratch)
 
 struct kw_runs {
   const uint64_t* p[KW_MAXK];
@@ -1372,13 +1378,14 @@ __global__ void kw_cuts_kernel(const uint64_t* __restrict__ base, uint32_t ntile
 // One tile of the merge.  MODE 0: rows -> columns; 1: count the tile's distinct rows; 2: rows -> columns, duplicates
 // dropped; 3: rows -> packed; 4: packed, duplicates dropped.  base[t] = output row of tile t (of the distinct rows in
 // the modes that drop duplicates); this launch writes relative to row out0.
-template <int MODE>
+template <int MODE, int TILE>
 __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const uint64_t* __restrict__ bounds, uint32_t tile0,
                                                              const uint64_t* __restrict__ base, uint64_t out0, int sb, int ob,
                                                              uint32_t* __restrict__ okey, uint32_t* __restrict__ osid,
                                                              uint32_t* __restrict__ ooff, uint64_t* __restrict__ opacked,
                                                              uint64_t* __restrict__ uniq, uint32_t* __restrict__ err) {
-  __shared__ uint64_t buf[KW_TMAX];
+  constexpr int TMAX = 3 * TILE, PER = TMAX / KW_THREADS;
+  __shared__ uint64_t buf[TMAX];
   __shared__ uint64_t s_lo[KW_MAXK];
   __shared__ uint32_t s_off[KW_MAXK + 1], s_w[KW_THREADS / 64 + 1];
   const uint32_t t = tile0 + blockIdx.x, k = R.k, tid = threadIdx.x, lane = tid & 63;
@@ -1402,8 +1409,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
   __syncthreads();
   // The plan bounds a tile below KW_TMAX rows.  Should it ever not, the tile says so: the host fails the merge and
   // marks the table (rows beyond the clamp would be lost, the columns would hold holes) -- never a silent drop.
-  if (s_off[k] > (uint32_t)KW_TMAX && tid == 0) atomicOr(err, 1u);
-  const uint32_t total = min(s_off[k], (uint32_t)KW_TMAX);
+  if (s_off[k] > (uint32_t)TMAX && tid == 0) atomicOr(err, 1u);
+  const uint32_t total = min(s_off[k], (uint32_t)TMAX);
   for (uint32_t r = 0; r < k; ++r) {
     const uint64_t* __restrict__ p = R.p[r] + s_lo[r];
     const uint32_t o = s_off[r], c = min(s_off[r + 1], total) - min(o, total);
@@ -1414,10 +1421,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
   // [s_off[q], s_off[q + stride]) and [s_off[q + stride], s_off[q + 2 stride]) -- each sorted -- become one.  A thread
   // produces `per` consecutive outputs: one binary search along its diagonal, then a serial merge of the two heads;
   // ties take the left (lower) run first.  Outputs wait in registers until every thread has read its inputs.
-  const uint32_t per = (total + KW_THREADS - 1) / KW_THREADS;          // uniform, <= KW_PER
+  const uint32_t per = (total + KW_THREADS - 1) / KW_THREADS;          // uniform, <= PER
   const uint32_t g0 = min(tid * per, total), g1 = min(g0 + per, total);
   for (uint32_t stride = 1; stride < k; stride <<= 1) {
-    uint64_t out[KW_PER];
+    uint64_t out[PER];
     uint32_t g = g0;
     while (g < g1) {                                                    // one piece per region the thread's outputs touch (1, rarely 2)
       uint32_t q = 0;
@@ -1432,7 +1439,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
       uint32_t i = lo, j = d - lo;
       uint64_t ca = i < na ? buf[a0 + i] : 0, cb = j < nb ? buf[mid + j] : 0;
 #pragma unroll
-      for (int c = 0; c < KW_PER; ++c) {
+      for (int c = 0; c < PER; ++c) {
         if ((uint32_t)c < per && (uint32_t)c >= c0 && (uint32_t)c < c0 + cnt) {
           const bool take_a = j >= nb || (i < na && ca <= cb);
           out[c] = take_a ? ca : cb;
@@ -1443,7 +1450,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < KW_PER; ++c)
+    for (int c = 0; c < PER; ++c)
       if ((uint32_t)c < per && g0 + c < g1) buf[g0 + c] = out[c];
     __syncthreads();
   }
@@ -1495,6 +1502,19 @@ __global__ __launch_bounds__(KW_THREADS) void kw_tile_kernel(kw_runs R, const ui
     __syncthreads();
   }
   if (MODE == 1 && tid == 0) uniq[t] = run;
+}
+
+// launch of one instantiation by the plan's tile size
+template <int MODE>
+static void kw_launch(hipStream_t st, uint32_t tile_rows, uint32_t grid, const kw_runs& R, const uint64_t* bounds, uint32_t tile0,
+                      const uint64_t* base, uint64_t out0, int sb, int ob, uint32_t* okey, uint32_t* osid, uint32_t* ooff,
+                      uint64_t* opacked, uint64_t* uniq, uint32_t* err) {
+  if (tile_rows == KW_TILE_SMALL)
+    hipLaunchKernelGGL((kw_tile_kernel<MODE, KW_TILE_SMALL>), dim3(grid), dim3(KW_THREADS), 0, st, R, bounds, tile0, base, out0, sb, ob, okey,
+                       osid, ooff, opacked, uniq, err);
+  else
+    hipLaunchKernelGGL((kw_tile_kernel<MODE, KW_TILE_LARGE>), dim3(grid), dim3(KW_THREADS), 0, st, R, bounds, tile0, base, out0, sb, ob, okey,
+                       osid, ooff, opacked, uniq, err);
 }
 
 // ---- host side of the bulk build ----
@@ -1627,7 +1647,8 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
   // plan: every M-th element of every run is a sample; every c-th of the sorted samples starts a tile
   uint32_t kp2 = 1;
   while (kp2 < k) kp2 <<= 1;
-  const uint32_t nominal = (uint32_t)std::min<uint64_t>(KW_TILE, std::max<uint64_t>(kp2, piece_rows / 8));
+  const uint32_t tile_rows = kp2 <= 16 ? KW_TILE_SMALL : KW_TILE_LARGE;
+  const uint32_t nominal = (uint32_t)std::min<uint64_t>(tile_rows, std::max<uint64_t>(kp2, piece_rows / 8));
   const uint32_t M = std::max<uint32_t>(1, nominal / kp2), c = kp2;
   uint64_t S = 0;
   for (uint32_t r = 0; r < k; ++r) {
@@ -1658,9 +1679,7 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     hipLaunchKernelGGL(kw_tile_rows_kernel, dim3(nblk((uint64_t)ntiles + 1)), dim3(256), 0, ctx->stream, cb, k, ntiles, (uint64_t*)rows);
   } else {   // a first pass over the tiles counts their distinct rows
     SHZ_HIP(ctx, hipMemsetAsync((uint64_t*)rows + ntiles, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(kw_tile_kernel<1>, dim3(ntiles), dim3(KW_THREADS), 0, ctx->stream, R, cb, 0u,
-                       (const uint64_t*)nullptr, (uint64_t)0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                       (uint64_t*)nullptr, (uint64_t*)rows, t->d_kw_err);
+    kw_launch<1>(ctx->stream, tile_rows, ntiles, R, cb, 0u, (const uint64_t*)nullptr, (uint64_t)0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)rows, t->d_kw_err);
   }
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)rows, (uint64_t*)base, (uint64_t)ntiles + 1, nullptr));
@@ -1683,7 +1702,7 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     if (bad) {
       t->broken = true;
       SHZ_FAIL(ctx, SHZ_E_STATE, "k-way merge: a tile outgrew its bound of %d rows (k = %u, stride %u); the table is incomplete and refuses further use",
-               KW_TMAX, k, M);
+               (int)(3 * tile_rows), k, M);
     }
     return SHZ_OK;
   };
@@ -1700,11 +1719,9 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     SHZ_TRY(carve_cols(t, nrows, &ck, &cs, &co, &from_slab));
     pc.lap(PH_COL_ALLOC);
     if (dedup)
-      hipLaunchKernelGGL(kw_tile_kernel<2>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
-                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
+      kw_launch<2>(ctx->stream, tile_rows, nt, R, cb, t0, (const uint64_t*)base, r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
     else
-      hipLaunchKernelGGL(kw_tile_kernel<0>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
-                         r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
+      kw_launch<0>(ctx->stream, tile_rows, nt, R, cb, t0, (const uint64_t*)base, r0, sb, ob, ck, cs, co, (uint64_t*)nullptr, (uint64_t*)nullptr, t->d_kw_err);
     SHZ_HIP(ctx, hipGetLastError());
     // the new segment is the active one until the next piece (or the caller) freezes it
     if (t->key && !t->act_slab) { void* olds[] = {t->key, t->sid, t->off}; for (void* p : olds) (void)hipFree(p); }
@@ -1725,11 +1742,9 @@ static int32_t kway_merge(shz_table* t, const std::vector<const uint64_t*>& ptr,
     if (nrows > rest_cap || !rest) SHZ_FAIL(ctx, SHZ_E_STATE, "k-way merge: %llu rows left over, room for %llu", (unsigned long long)nrows, (unsigned long long)rest_cap);
     if (nrows) {
       if (dedup)
-        hipLaunchKernelGGL(kw_tile_kernel<4>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
-                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
+        kw_launch<4>(ctx->stream, tile_rows, nt, R, cb, t0, (const uint64_t*)base, r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
       else
-        hipLaunchKernelGGL(kw_tile_kernel<3>, dim3(nt), dim3(KW_THREADS), 0, ctx->stream, R, cb, t0, (const uint64_t*)base,
-                           r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
+        kw_launch<3>(ctx->stream, tile_rows, nt, R, cb, t0, (const uint64_t*)base, r0, sb, ob, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, rest, (uint64_t*)nullptr, t->d_kw_err);
       SHZ_HIP(ctx, hipGetLastError());
     }
     if (rest_rows) *rest_rows = nrows;
