@@ -138,3 +138,43 @@ def test_workspace_limit_is_enforced_not_ignored(env):
         ctx.set_workspace_limit(0)
     k, t1, ho, n = ctx.fingerprint_batch(y, off)    # and the context is usable again afterwards
     assert n == len(k) > 3000
+
+
+def test_round4_entry_points_refuse_bad_arguments(env):
+    """The entry points added in round 4: NULL handles, out-of-range values and objects of different contexts come back as
+    SHZ_E_* codes; a refused shz_set_overlap leaves the window as it was."""
+    S, _ffi, ctx, x = env
+    L = _ffi.lib()
+    p = _ffi.vp()
+    assert L.shz_host_alloc(None, 64, C.byref(p)) == _ffi.E_INVALID
+    assert L.shz_host_alloc(ctx.h, 64, None) == _ffi.E_INVALID
+    assert L.shz_host_free(None, None) == _ffi.OK                    # nothing to free
+    assert L.shz_upload_stats(None, None, None, None, None) == _ffi.E_INVALID
+    assert L.shz_comm_warmup(None) == _ffi.E_INVALID
+    assert L.shz_table_exchange_run(None, None) == _ffi.E_INVALID
+    assert L.shz_table_exchange_stats(None, None, None, None, None) == _ffi.E_INVALID
+    assert L.shz_table_set_run_rows(None, 100) == _ffi.E_INVALID
+    assert L.shz_frame_count_hop(10 * 4096, 0) == 0 and L.shz_frame_count_hop(10 * 4096, 4097) == 0
+    assert L.shz_frame_count_hop(10 * 4096, 4096) == 10 and L.shz_frame_count_hop(4095, 17) == 1
+    # overlap: mlab's rule (noverlap < NFFT); a refusal changes nothing
+    before = S.fingerprint(x)
+    assert L.shz_set_overlap(ctx.h, 4096) == _ffi.E_INVALID and L.shz_set_overlap(None, 2048) == _ffi.E_INVALID
+    assert S.fingerprint(x) == before
+    with pytest.raises(ValueError):
+        S.fingerprint(x, wratio=-0.1)
+    # run rows: 0 (the limit of a sort) or >= 16
+    tbl = S.Table(ctx)
+    assert L.shz_table_set_run_rows(tbl.h, 5) == _ffi.E_INVALID and L.shz_table_set_run_rows(tbl.h, 0) == _ffi.OK
+    # a table and a communicator of different contexts do not go together
+    ctx2 = _ffi.Context(0)
+    comm2 = _ffi.Comm.local(ctx2, 4711, 0, 1)
+    assert L.shz_table_exchange_run(tbl.h, comm2.h) == _ffi.E_INVALID
+    b = C.c_uint64()
+    assert L.shz_table_allgather(tbl.h, comm2.h, C.byref(b)) == _ffi.E_INVALID
+    # membw: the host link modes exist, a mode beyond them does not
+    gb = C.c_float()
+    assert L.shz_membw(ctx.h, 6, 1 << 20, 1, C.byref(gb)) == _ffi.E_INVALID
+    assert L.shz_membw(ctx.h, 3, 8 << 20, 1, C.byref(gb)) == _ffi.OK and gb.value > 1.0
+    comm2.close()
+    ctx2.close()
+    tbl.close()
