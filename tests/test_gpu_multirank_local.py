@@ -280,6 +280,22 @@ def test_sharded_builder_over_thread_ranks_equals_one_rank():
 
     ref_rows, ref_info, ref_segs = run(1, 0, lambda ctx: None)
     assert ref_info["runs_sealed_on_the_way"] >= 2 and ref_segs >= 2
+    # the same corpus handed over as HOST arrays (what read() yields, __init__.py:70-113): the same table
+    hctx = _ffi.Context(0)
+    hdb = HipFingerprintDB(ctx=hctx)
+    hdb.table.set_segment_rows(9000)
+
+    def host_source(lo, hi):
+        buf = hctx.synth_pcm(4242, lo, hi - lo, n_samples, 3000, 1500)
+        pcm = buf.download(np.int16, (hi - lo) * n_samples)
+        buf.free()
+        return [pcm[i * n_samples:(i + 1) * n_samples] for i in range(hi - lo)]
+
+    ShardedBuilder(hdb, 0, 1, None, chunk_tracks=4, seal_rows=3000).build(n_tracks, host_source)
+    hk, hs, ho_ = hdb.table.export()
+    assert np.array_equal(np.stack([hk, hs, ho_], 1).astype(np.uint64), ref_rows)
+    hdb.close()
+    hctx.close()
     outs = _run_ranks(world, lambda r: run(world, r, lambda ctx: _ffi.Comm.local(ctx, 777001, r, world)))
     for rows, info, segs in outs:
         assert np.array_equal(rows, ref_rows)           # same rows in the same order: segments cut by key range concatenate to the sorted table
