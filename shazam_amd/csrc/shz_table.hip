@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
   constexpr int VW_S2 = 1 << VW_B2;
   constexpr uint32_t VW_LIMIT2 = VW_S2 - 68;        // + one row of new songs stays below VW_S2
   static_assert(VW_LIMIT2 + 64 < (uint32_t)VW_S2 && VW_LIMIT1 + 64 < VW_S1, "a probe must find a free slot in either table");
-  uint32_t st_b = 0, st_over = 0, st_seed = 0, st_beat = 0, st_votes_redo = 0;   // SHZ_VT_STATS
+  uint32_t st_b = 0, st_seed = 0, st_beat = 0, st_votes_redo = 0;   // SHZ_VT_STATS
   __shared__ uint4 t1[VW_S1 / 2];                    // key1[VW_S1] | cnt[VW_S1]
   __shared__ uint4 t2[VW_S2];                        // key2[VW_S2] | ded[VW_S2] | best[VW_S2] (8 bytes each)
   uint32_t* const key1 = (uint32_t*)t1;
@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     consume();
     end_batch(b, 0xFFFFFFFFu);
     if (stats && lane == 0) {
-      atomicAdd(stats + 0, (unsigned long long)st_b); atomicAdd(stats + 1, (unsigned long long)st_over);
+      atomicAdd(stats + 0, (unsigned long long)st_b);
       atomicAdd(stats + 2, (unsigned long long)st_seed); atomicAdd(stats + 3, (unsigned long long)st_beat);
       atomicAdd(stats + 6, (unsigned long long)st_votes_redo); atomicAdd(stats + 7, (unsigned long long)(b - a));
     }
@@ -2141,8 +2141,8 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
     unsigned long long h[8];
     SHZ_HIP(ctx, hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
     SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    fprintf(stderr, "[vt_stats] tiles %u few_songs %d batches %llu overflow %llu count1 %llu beat %llu votes_redone %llu votes %llu\n",
-            nt, (int)few_songs, h[0], h[1], h[2], h[3], h[6], h[7]);
+    fprintf(stderr, "[vt_stats] tiles %u few_songs %d batches %llu count1 %llu beat %llu votes_redone %llu votes %llu\n",
+            nt, (int)few_songs, h[0], h[2], h[3], h[6], h[7]);
   }
   hipLaunchKernelGGL(vt_fold_kernel, dim3(std::min<uint32_t>(hcap, 64u)),
                      dim3(VT_THREADS), 0, ctx->stream, ks, (const uint2*)heavy, (const uint32_t*)n_heavy, hcap, pl, topn,
