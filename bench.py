@@ -530,7 +530,7 @@ def match_1m(ctx, songs, info):
     t0 = time.perf_counter()
     # a run every 1/16 of the corpus: 16 runs are what the k-way merge takes with its small tiles (1.13e10 rows: plan + merge 0.13 s;
     # 20 runs: 0.39 s), and the batch (7.4e8 rows) still fits the arena beside the held runs
-    tbl, build, bufs = bench_db.build_table(ctx, songs, 30.0, 1000, 4000, 1500, finalize_every=max(1000, songs // 16 // 1000 * 1000))
+    tbl, build, bufs = bench_db.build_table(ctx, songs, 30.0, 1000, 4000, 1500, finalize_every=max(1000, -(-songs // 16000) * 1000))   # (rounded UP to whole chunks: 16 runs, not 17)
     n_samples = 30 * FS
     qn = 10 * FS
     o = {"songs": songs, "rows": build["rows"], "build_seconds": build["seconds_total"],
