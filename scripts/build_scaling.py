@@ -18,25 +18,14 @@ import types
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--songs", type=int, default=100000)
-    ap.add_argument("--seconds", type=float, default=180.0)
-    ap.add_argument("--local-ranks", type=int, default=1)
-    a = ap.parse_args()
+def run_local(songs, seconds, world):
+    """bench.db_build_scaling with `world` thread ranks on one GPU (in-process transport); returns every rank's result."""
     import bench
     from shazam_amd import _ffi
-    args = types.SimpleNamespace(scaling_songs=a.songs, scaling_seconds=a.seconds)
-    if a.local_ranks <= 1:
-        ctx = _ffi.Context(0)
-        t0 = time.perf_counter()
-        o = bench.db_build_scaling(args, ctx, None, None, 0, 1)
-        o["wall_incl_setup_s"] = time.perf_counter() - t0
-        print(json.dumps(o))
-        return
-    world = a.local_ranks
+    args = types.SimpleNamespace(scaling_songs=songs, scaling_seconds=seconds)
     bar = threading.Barrier(world)
     outs, errs = [None] * world, [None] * world
+    gid = 31337 + int(time.time() * 1e3) % 100000
 
     class Dist:   # what db_build_scaling needs of torch.distributed, between threads
         class ReduceOp:
@@ -60,7 +49,7 @@ def main():
     def go(r):
         try:
             ctx = _ffi.Context(0)
-            comm = _ffi.Comm.local(ctx, 31337, r, world)
+            comm = _ffi.Comm.local(ctx, gid, r, world)
             outs[r] = bench.db_build_scaling(args, ctx, Dist(r), comm, r, world)
             comm.close()
             ctx.close()
@@ -76,8 +65,28 @@ def main():
     for e in errs:
         if e is not None:
             raise e
+    return outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--songs", type=int, default=100000)
+    ap.add_argument("--seconds", type=float, default=180.0)
+    ap.add_argument("--local-ranks", type=int, default=1)
+    a = ap.parse_args()
+    import bench
+    from shazam_amd import _ffi
+    args = types.SimpleNamespace(scaling_songs=a.songs, scaling_seconds=a.seconds)
+    if a.local_ranks <= 1:
+        ctx = _ffi.Context(0)
+        t0 = time.perf_counter()
+        o = bench.db_build_scaling(args, ctx, None, None, 0, 1)
+        o["wall_incl_setup_s"] = time.perf_counter() - t0
+        print(json.dumps(o))
+        return
+    outs = run_local(a.songs, a.seconds, a.local_ranks)
     o = outs[0]
-    o["transport"] = f"{world} thread ranks on one GPU (in-process transport)"
+    o["transport"] = f"{a.local_ranks} thread ranks on one GPU (in-process transport)"
     o["rows_all_ranks"] = [x["rows"] for x in outs]
     print(json.dumps(o))
 
