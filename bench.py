@@ -468,7 +468,9 @@ def db_build_scaling(a, ctx, dist, comm, rank, world):
     t_wall = time.perf_counter() - t_all0
     t_synth = synth_ms[0] / 1e3
     vals = [t_wall - t_synth, info["fingerprint_s"], info["insert_s"], info["seal_exchange_s"], info["final_s"], t_synth, t_reserve]
-    if dist:
+    if dist and hasattr(dist, "max_floats"):   # (the thread-rank harness: no torch in that process)
+        vals = dist.max_floats(vals)
+    elif dist:
         import torch
         tt = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -606,6 +608,9 @@ def main():
     if world > 1:
         # torch.distributed is rendezvous plumbing only (barrier, max, id broadcast) on gloo/CPU;
         # the data path collective is RCCL called from libshz.so.
+        # ORDER MATTERS: torch brings its own copy of the HIP runtime and of RCCL.  Imported BEFORE libshz.so is loaded, the whole
+        # process -- libshz.so included -- binds to that one copy and everything works (scripts/rccl_probe.py).  Imported AFTER
+        # it, the process holds two HIP runtimes and ncclCommInitRank fails ("unhandled cuda error").  So: torch first, here.
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -27,9 +27,8 @@ def run_local(songs, seconds, world):
     outs, errs = [None] * world, [None] * world
     gid = 31337 + int(time.time() * 1e3) % 100000
 
-    class Dist:   # what db_build_scaling needs of torch.distributed, between threads
-        class ReduceOp:
-            MAX = "max"
+    class Dist:   # what db_build_scaling needs of a process group, between threads -- WITHOUT torch: a process that has loaded
+        # libshz.so (the system's HIP runtime) must not load torch's bundled HIP runtime and RCCL afterwards
         vals = [None] * world
 
         def __init__(self, r):
@@ -38,13 +37,12 @@ def run_local(songs, seconds, world):
         def barrier(self):
             bar.wait()
 
-        def all_reduce(self, t, op=None):
-            Dist.vals[self.r] = t.clone()
+        def max_floats(self, v):
+            Dist.vals[self.r] = list(v)
             bar.wait()
-            import torch
-            m = torch.stack(Dist.vals).max(0).values
+            m = [max(x[i] for x in Dist.vals) for i in range(len(v))]
             bar.wait()
-            t.copy_(m)
+            return m
 
     def go(r):
         try:
