@@ -258,7 +258,7 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
     from shazam_amd import Table
     tbl = Table(ctx)
     comm = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         ids = [_ffi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = _ffi.Comm(ctx, ids[0], rank, world)
@@ -281,8 +281,8 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
                        "seconds_incl_fingerprint": t_build + elapsed / a.steps,
                        "songs_per_second_incl_fingerprint": world * nc / (t_build + elapsed / a.steps),
                        "allgather_bytes_received": int(recv),
-                       "collective": (f"RCCL all-gather-v of the ranks' sorted packed runs (8 B/row, pieces <= 1 GB, "
-                                      f"pattern {os.environ.get('SHZ_ALLGATHER', 'sendrecv')}), then {world}-way merge") if comm else None,
+                       "collective": ("exchange rounds over RCCL: every rank's sorted packed runs (8 B/row, pieces <= 1 GB, grouped "
+                                      "ncclSend / ncclRecv on the communicator's own stream) to every peer, then one k-way merge of all runs") if comm else None,
                        "build_stats_s": tbl.build_stats() if comm else None}
     # STRONG scaling of the database build (north star: >= 6x at 8 GPUs): ONE fixed corpus, the same at every N, split in
     # contiguous blocks (ingest.shard_tracks), fingerprint -> RCCL all-gather of the sorted runs -> k-way merge -> table.
@@ -290,7 +290,7 @@ def extras(a, ctx, dist, rank, world, nc, n_samples, kbuf, tbuf, hash_off, elaps
     # fingerprint_directory (__init__.py:335-357).
     # (one GPU: run after the 1M-song table below -- that one reserves 250 GB beside its first chunks, and on memory nothing in
     # this process has freed yet the reservation costs nothing; the scaling build reserves outside its clock either way)
-    if a.scaling_songs > 0 and world > 1:
+    if a.scaling_songs > 0 and (world > 1 or a.force_dist):
         try:
             out["db_build_scaling"] = db_build_scaling(a, ctx, dist, comm, rank, world)
         except Exception as e:  # noqa: BLE001
@@ -594,6 +594,8 @@ def main():
     ap.add_argument("--scaling-songs", type=int, default=100000, help="fixed corpus of the db_build_scaling extra: the same "
                     "at every --gpus N (0 = skip)")
     ap.add_argument("--scaling-seconds", type=float, default=180.0, help="track length of that corpus (BASELINE configs[2]: 3 min)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal on one GPU: take the N > 1 branches (torch first, gloo group, "
+                    "RCCL communicator, gathered builds, max over ranks) with ONE rank")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -605,7 +607,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with "
                          f"torch.distributed.run --nproc-per-node {a.gpus} or without a launcher")
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         # torch.distributed is rendezvous plumbing only (barrier, max, id broadcast) on gloo/CPU;
         # the data path collective is RCCL called from libshz.so.
         # ORDER MATTERS: torch brings its own copy of the HIP runtime and of RCCL.  Imported BEFORE libshz.so is loaded, the whole
@@ -750,7 +755,7 @@ def main():
                 out["match_1M"] = match_1m(ctx, a.match_songs, info)
             except Exception as e:  # noqa: BLE001
                 out["match_1M"] = {"error": repr(e)}
-        if world == 1 and a.scaling_songs > 0:
+        if world == 1 and a.scaling_songs > 0 and not a.force_dist:
             try:
                 out["db_build_scaling"] = db_build_scaling(a, ctx, None, None, 0, 1)
             except Exception as e:  # noqa: BLE001
