@@ -196,6 +196,14 @@ int32_t shz_upload_stats(shz_ctx* ctx, uint64_t* chunks, uint64_t* bytes, double
  * noverlap >= 4096: SHZ_E_INVALID (mlab raises ValueError, mlab:242).  Other wsize: not implemented -- the Python layer raises
  * NotImplementedError, there is no CPU fallback. */
 int32_t shz_set_overlap(shz_ctx* ctx, uint32_t noverlap);
+/* mlab.specgram(x, NFFT=nfft, Fs, window_hanning, noverlap)[0] -> 10*log10 where != 0 (__init__.py:232-241) for window sizes
+ * OTHER than 4096: nfft a power of two in [64, 2048].  A generic kernel (one workgroup per frame, radix-2 in fp64) -- correct,
+ * not fast; the reference and every caller of it use 4096.  pcm: host, one channel; out_db: host [nfft/2 + 1][n_frames]
+ * (the reference's layout), cap_doubles its capacity; SHZ_STFT_POWER: the PSD instead of dB.  With shz_peaks_from_db and
+ * shz_pair_hash this is fingerprint(wsize=nfft) as the reference composes it.  Other sizes: SHZ_E_UNSUPPORTED (8192 has no
+ * packed key: key32 gives a frequency 12 bits; non-powers of two are not implemented). */
+int32_t shz_stft_db_any(shz_ctx* ctx, const int16_t* pcm, uint64_t n_samples, uint32_t fs, uint32_t nfft, uint32_t noverlap,
+                        uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* n_frames);
 uint32_t shz_frame_count_hop(uint64_t n_samples, uint32_t hop);
 
 /* Staging precision of shz_peaks / shz_fingerprint_batch.  Default (0): the power spectrogram is staged in fp32 and

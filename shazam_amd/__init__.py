@@ -147,10 +147,11 @@ def _check_window(wsize, wratio) -> int:
         raise ValueError("noverlap must be less than NFFT")
     if noverlap < 0:
         raise ValueError("wratio must not be negative")
-    if int(wsize) != DEFAULT_WINDOW_SIZE:
-        raise NotImplementedError("the HIP STFT kernel is built for wsize=4096 (the reference's only window size: its radix plan, "
-                                  "LDS layout and 2049-bin peak stage); any wratio is taken, other window sizes are not implemented "
-                                  "and there is no CPU fallback")
+    w = int(wsize)
+    if w != DEFAULT_WINDOW_SIZE and (w < 64 or w > 2048 or (w & (w - 1))):
+        raise NotImplementedError("window sizes: 4096 (the reference's own, the fast kernel) and the powers of two 64 .. 2048 (a "
+                                  "generic GPU spectrogram); 8192 has no packed key (key32 gives a frequency 12 bits), other sizes "
+                                  "are not implemented, and there is no CPU fallback")
     return noverlap
 
 
@@ -181,8 +182,13 @@ def fingerprint(channel_samples, Fs: int = RATE, wsize: int = DEFAULT_WINDOW_SIZ
                 fan_value: int = DEFAULT_FAN_VALUE, amp_min: int = DEFAULT_AMP_MIN):
     """__init__.py:212-245: FFT the channel, log transform, local maxima, pair hashes.
     Returns list[(hex20, t1)] in the reference's generation order."""
-    _check_window(wsize, wratio)
+    noverlap = _check_window(wsize, wratio)
     ctx = get_context()
+    if int(wsize) != DEFAULT_WINDOW_SIZE:
+        # another window size: the reference's own composition (__init__.py:232-245) of GPU stages -- generic spectrogram,
+        # get_2D_peaks on the dB array, generate_hashes on the peaks
+        arr2D = ctx.stft_db_any(_as_pcm(channel_samples), int(Fs), int(wsize), noverlap)
+        return generate_hashes(get_2D_peaks(arr2D, plot=False, amp_min=amp_min), fan_value=fan_value)
     k, t1, _ = fingerprint_batch([channel_samples], Fs, fan_value, amp_min, ctx, wratio)
     return list(zip(hex_of_keys(ctx, k), t1.tolist()))
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_frame_count_hop": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "shz_set_overlap": (C.c_int32, [vp, C.c_uint32]),
+    "shz_stft_db_any": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
     "shz_peaks": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, vp, vp, u64p, C.c_uint64, u64p]),
@@ -406,6 +407,18 @@ class Context:
             res.append(out[pos:pos + f * NBINS].reshape(NBINS, f))
             pos += f * NBINS
         return res
+
+    def stft_db_any(self, x, fs=44100, nfft=2048, noverlap=1024, power=False) -> np.ndarray:
+        """dB spectrogram [nfft/2 + 1, frames] of one channel for a window size other than 4096 (generic kernel)."""
+        x = np.ascontiguousarray(x, np.int16)
+        n = len(x)
+        hop = int(nfft) - int(noverlap)
+        frames = 1 if n < nfft or hop <= 0 else (n - int(nfft)) // hop + 1
+        out = np.empty((int(nfft) // 2 + 1) * max(frames, 1), np.float64)
+        nf = C.c_uint64()
+        self.check(lib().shz_stft_db_any(self.h, ptr(x), n, int(fs), int(nfft), int(noverlap), STFT_POWER if power else 0, ptr(out),
+                                         out.size, C.byref(nf)))
+        return out[:(int(nfft) // 2 + 1) * nf.value].reshape(int(nfft) // 2 + 1, nf.value)
 
     def peaks(self, pcm, clip_off, fs=44100, amp_min=10.0, pcm_device=False):
         co, nc = self._clip_off(clip_off)

@@ -1406,6 +1406,97 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Window sizes other than 4096 (fingerprint(..., wsize=...), __init__.py:212-217, 232-237): a GENERIC spectrogram, correct
+// and not fast -- nobody's hot path: the reference and all its callers use 4096.  One workgroup per frame, radix-2 Stockham
+// through two LDS buffers in fp64, window and twiddles from tables the host computes in long double; mlab's scaling
+// (mlab:339-354) and the reference's log rule (__init__.py:241).  Output in the reference's [bins][frames] layout, so that
+// get_2D_peaks / generate_hashes (shz_peaks_from_db, shz_pair_hash) take it from there as the reference's own fingerprint()
+// composes them.  nfft: a power of two in [64, 2048] (two buffers of nfft complex doubles are 64 KB of LDS at 2048; 8192 has
+// no packed key: key32 gives a frequency 12 bits).
+__global__ __launch_bounds__(256) void stft_any_kernel(const int16_t* __restrict__ pcm, uint64_t n, uint32_t nfft, uint32_t hop,
+                                                       uint32_t F, const double* __restrict__ window, const cplx* __restrict__ tw,
+                                                       double scale, int as_power, double* __restrict__ out) {
+  extern __shared__ cplx gs_lds[];
+  cplx* a = gs_lds;
+  cplx* b = gs_lds + nfft;
+  const uint32_t f = blockIdx.x, tid = threadIdx.x, half = nfft >> 1;
+  const uint64_t s0 = (uint64_t)f * hop;
+  for (uint32_t i = tid; i < nfft; i += 256) {
+    const uint64_t sidx = s0 + i;
+    const double x = sidx < n ? (double)pcm[sidx] : 0.0;   // (only a clip shorter than one window is padded, mlab:268-271)
+    a[i] = make_double2(x * window[i], 0.0);
+  }
+  __syncthreads();
+  for (uint32_t Ns = 1; Ns < nfft; Ns <<= 1) {
+    const uint32_t tstep = nfft / (2 * Ns);   // W_{2 Ns}^k = W_nfft^(k tstep)
+    for (uint32_t j = tid; j < half; j += 256) {
+      const uint32_t k = j & (Ns - 1);
+      const cplx u = a[j], v = cmul(a[j + half], tw[k * tstep]);
+      const uint32_t j0 = ((j - k) << 1) + k;
+      b[j0] = cadd(u, v);
+      b[j0 + Ns] = csub(u, v);
+    }
+    __syncthreads();
+    cplx* t = a; a = b; b = t;
+  }
+  for (uint32_t k = tid; k <= half; k += 256) {
+    const cplx X = a[k];
+    const double sc = (k != 0 && k != half) ? 2.0 * scale : scale;
+    const double p = fma(X.x, X.x, X.y * X.y) * sc;
+    out[(uint64_t)k * F + f] = as_power ? p : (p != 0.0 ? shz_db_of(p) : 0.0);
+  }
+}
+
+extern "C" int32_t shz_stft_db_any(shz_ctx* ctx, const int16_t* pcm, uint64_t n_samples, uint32_t fs, uint32_t nfft, uint32_t noverlap,
+                                   uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* n_frames) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (n_frames) *n_frames = 0;
+  if (!pcm && n_samples) SHZ_FAIL(ctx, SHZ_E_INVALID, "pcm is NULL");
+  if (fs == 0) SHZ_FAIL(ctx, SHZ_E_INVALID, "fs must be positive");
+  if (nfft < 64 || nfft > 2048 || (nfft & (nfft - 1)))
+    SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "the generic spectrogram takes window sizes 64, 128, ..., 2048 (4096 is shz_stft_db; got %u)", nfft);
+  if (noverlap >= nfft) SHZ_FAIL(ctx, SHZ_E_INVALID, "noverlap must be less than NFFT (%u >= %u)", noverlap, nfft);   // mlab:242
+  if (n_samples == 0) SHZ_FAIL(ctx, SHZ_E_INVALID, "no samples");
+  const uint32_t hop = nfft - noverlap;
+  const uint64_t F64 = n_samples < nfft ? 1 : (n_samples - nfft) / hop + 1;   // mlab:268-271, 307-308
+  if (F64 > (1ull << 24)) SHZ_FAIL(ctx, SHZ_E_UNSUPPORTED, "%llu frames", (unsigned long long)F64);
+  const uint32_t F = (uint32_t)F64, bins = nfft / 2 + 1;
+  if (n_frames) *n_frames = F;
+  if ((uint64_t)F * bins > cap_doubles || !out_db) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_stft_db_any: need %llu doubles", (unsigned long long)F * bins);
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  // tables: np.hanning(nfft) (symmetric, mlab:58-66) and W_nfft^k, in long double like the 4096 tables of the context
+  std::vector<double> win(nfft);
+  std::vector<cplx> tw(nfft / 2);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  double sumsq = 0.0;
+  for (uint32_t i = 0; i < nfft; ++i) {
+    const long double nn = (long double)(1 - (long)nfft + 2 * (long)i);
+    win[i] = (double)(0.5L + 0.5L * cosl(pi * nn / (long double)(nfft - 1)));
+  }
+  for (uint32_t i = 0; i < nfft; ++i) sumsq += win[i] * win[i];
+  for (uint32_t k = 0; k < nfft / 2; ++k) {
+    const long double ang = -2.0L * pi * (long double)k / (long double)nfft;
+    tw[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+  }
+  void *d_pcm, *d_win, *d_tw, *d_out;
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PCM, n_samples * 2 + 64, &d_pcm));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, (uint64_t)nfft * 8 + 64, &d_win));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)nfft * 8 + 64, &d_tw));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)F * bins * 8 + 64, &d_out));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_pcm, pcm, n_samples * 2, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_win, win.data(), (uint64_t)nfft * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_tw, tw.data(), (uint64_t)nfft * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the host tables go out of scope)
+  const double scale = 1.0 / ((double)fs * sumsq);   // P / Fs / sum(w^2), mlab:350-354
+  hipLaunchKernelGGL(stft_any_kernel, dim3(F), dim3(256), (size_t)nfft * 2 * sizeof(cplx), ctx->stream, (const int16_t*)d_pcm, n_samples,
+                     nfft, hop, F, (const double*)d_win, (const cplx*)d_tw, scale, (flags & SHZ_STFT_POWER) ? 1 : 0, (double*)d_out);
+  SHZ_HIP(ctx, hipGetLastError());
+  SHZ_HIP(ctx, shz_memcpy(ctx, out_db, d_out, (uint64_t)F * bins * 8, hipMemcpyDeviceToHost));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The batch path: shz_peaks / shz_fingerprint_batch.  One pass = every sub-batch queued on the stream with NO host
 // read-back in between: peak counts, hash counts, output offsets and overflow flags live in the device control block
 // (xctl) and come back with ONE copy + sync at the end.  List capacities are estimates; a pass whose flags say that an

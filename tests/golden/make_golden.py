@@ -158,7 +158,10 @@ VARIANTS = {"amp0": dict(amp_min=0), "amp25": dict(amp_min=25), "ampneg5": dict(
             "fan2": dict(fan_value=2), "fan10": dict(fan_value=10), "fan1": dict(fan_value=1),
             "fs8000": dict(Fs=8000), "fs48000": dict(Fs=48000),
             # wratio: noverlap = int(4096 * wratio), hop = 4096 - noverlap (round 4): 1024, 3072, 4096 and the odd 411
-            "wr075": dict(wratio=0.75), "wr025": dict(wratio=0.25), "wr0": dict(wratio=0.0), "wr08999": dict(wratio=0.8999)}
+            "wr075": dict(wratio=0.75), "wr025": dict(wratio=0.25), "wr0": dict(wratio=0.0), "wr08999": dict(wratio=0.8999),
+            # wsize: the generic spectrogram (powers of two 64 .. 2048), alone and with wratio
+            "ws2048": dict(wsize=2048), "ws1024": dict(wsize=1024), "ws512_wr075": dict(wsize=512, wratio=0.75),
+            "ws256_wr0": dict(wsize=256, wratio=0.0), "ws64": dict(wsize=64), "ws2048_fs8000": dict(wsize=2048, Fs=8000)}
 
 
 def param_variants(ref):
@@ -171,6 +174,14 @@ def param_variants(ref):
         var[f"{tag}_hash_hex"] = np.array([h for h, _ in hs], dtype="S20")
         var[f"{tag}_hash_t1"] = np.array([int(o) for _, o in hs], np.int64)
         print("variant", tag, len(hs), "hashes")
+    # the reference's own spectrogram lines (__init__.py:232-241) for two of the window sizes, on a short piece: the dB array
+    from matplotlib import mlab
+    for tag, nfft, nov, n in (("ws1024", 1024, 512, 1024 * 9 + 77), ("ws256", 256, 0, 256 * 12 + 3), ("ws2048short", 2048, 1024, 1500)):
+        a = mlab.specgram(xv[:n], NFFT=nfft, Fs=44100, window=mlab.window_hanning, noverlap=nov)[0]
+        with np.errstate(divide="ignore"):
+            a = 10 * np.log10(a, out=np.zeros_like(a), where=(a != 0))
+        var[f"{tag}_db"] = a
+        var[f"{tag}_db_args"] = np.array([nfft, nov, n], np.int64)
     np.savez_compressed(os.path.join(HERE, "param_variants.npz"), **var)
 
 

@@ -37,4 +37,4 @@ def test_registry_mirrors_reference():
     with pytest.raises(TypeError, match="Unsupported database type supplied."):
         S.get_database("nope")
     with pytest.raises(NotImplementedError):
-        S.fingerprint([0, 1, 2], wsize=2048)
+        S.fingerprint([0, 1, 2], wsize=8192)
