@@ -54,8 +54,9 @@ def build_table(ctx, songs, seconds=30.0, chunk=1000, tone_amp=4000, noise_amp=1
     reserved up front it adds its own time (1M x 30 s, 250 GB: reserve 5.7 s + fingerprint 6.4 s; seconds_total 20.0), beside
     the first chunks it stretches them instead (fingerprint 8.8 s, seconds_total 16.8) -- the second is what is done.
     overlap_synth (off): chunk i + 1 synthesised by a second context (own stream, second PCM buffer) while chunk i is
-    fingerprinted and inserted.  Measured at 1M x 30 s: 13.0 s against 6.43 + 6.88 s one after the other -- synthesis and
+    fingerprinted and inserted.  Measured at 1M x 30 s (with the round-3 generator): 13.0 s against 6.43 + 6.88 s one after the other -- synthesis and
     the STFT are both bound by the vector ALU and only share the chip; left off so that fingerprint_s means fingerprinting.
+    (The generator now takes 2.8 s for the same tracks.)
     Returns (table, stats); song ids are track index + 1 (mysql_database.py:34,200)."""
     from shazam_amd import _ffi, Table
     n_samples = int(round(seconds * FS))

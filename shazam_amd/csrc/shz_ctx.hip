@@ -427,36 +427,72 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 #define SYN_OM_MIN 10713046u
 #define SYN_OM_MAX 428521855u
 
-// one thread = 8 consecutive samples (one 16-byte store); grid.y = clip
+// one thread = 8 consecutive samples (one 16-byte store); grid.y = clip.  The six partials of a note (2^14 samples) are drawn
+// once per thread when its eight samples lie in one note (they do unless `start` is odd against the note grid), phases advance
+// in 32-bit arithmetic (only the low word of r + m * om is used), and the sine table sits in LDS: 1M x 30 s tracks took 6.9 s
+// with the per-sample form below (seven splitmix64 and six cached global gathers a sample), which was longer than
+// fingerprinting them.  Same values, bit for bit (tests/test_gpu_synth.py against oracle/synth.py).
+__device__ __forceinline__ long long synth_tone_sample(uint64_t key, uint64_t n, const int16_t* lut) {
+  const uint64_t seg = n >> SYN_NOTE_SHIFT, m = n & ((1u << SYN_NOTE_SHIFT) - 1);
+  long long s = 0;
+#pragma unroll
+  for (int k = 0; k < SYN_NPART; ++k) {
+    uint64_t r = splitmix64(~key + seg * 8 + (uint64_t)k);
+    uint64_t om = (uint64_t)SYN_OM_MIN + (((r >> 32) * (uint64_t)(SYN_OM_MAX - SYN_OM_MIN)) >> 32);
+    uint32_t ph = (uint32_t)(r + m * om);
+    s += lut[ph >> 20];
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(256) void synth_pcm_kernel(int16_t* __restrict__ out, uint64_t seed, uint64_t clip0,
                                                         uint64_t n_samples, uint64_t start, int tone_amp,
                                                         int noise_amp, const int16_t* __restrict__ lut) {
+  __shared__ int16_t s_lut[4096];
+  if (tone_amp > 0) {
+    for (int i = threadIdx.x; i < 4096 / 8; i += 256)
+      reinterpret_cast<uint4*>(s_lut)[i] = reinterpret_cast<const uint4*>(lut)[i];
+    __syncthreads();
+  }
   const uint64_t clip = blockIdx.y;
   const uint64_t key = splitmix64(seed * 0xD6E8FEB86659FD93ull + clip0 + clip);
   int16_t* dst = out + clip * n_samples;
   for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; base < n_samples;
        base += (uint64_t)gridDim.x * blockDim.x * 8) {
+    const uint64_t n0 = start + base;
+    int tone[8];
+    if (tone_amp > 0) {
+      if (((n0 + 7) >> SYN_NOTE_SHIFT) == (n0 >> SYN_NOTE_SHIFT)) {
+        const uint64_t seg = n0 >> SYN_NOTE_SHIFT;
+        const uint32_t m0 = (uint32_t)(n0 & ((1u << SYN_NOTE_SHIFT) - 1));
+        int s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < SYN_NPART; ++k) {
+          const uint64_t r = splitmix64(~key + seg * 8 + (uint64_t)k);
+          const uint32_t om = SYN_OM_MIN + (uint32_t)(((r >> 32) * (uint64_t)(SYN_OM_MAX - SYN_OM_MIN)) >> 32);
+          uint32_t ph = (uint32_t)r + m0 * om;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s[i] += s_lut[ph >> 20];
+            ph += om;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tone[i] = (int)(((long long)s[i] * tone_amp) >> 17);
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) tone[i] = (int)((synth_tone_sample(key, n0 + i, s_lut) * tone_amp) >> 17);
+      }
+    }
     int16_t v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const uint64_t n = start + base + i;
-      long long acc = 0;
+      int acc = 0;
       if (noise_amp > 0) {
-        uint64_t u = splitmix64(key + n) >> 32;
-        acc += (long long)((u * (uint64_t)(2 * noise_amp)) >> 32) - noise_amp;
+        const uint32_t u = (uint32_t)(splitmix64(key + n0 + i) >> 32);
+        acc += (int)(((uint64_t)u * (uint32_t)(2 * noise_amp)) >> 32) - noise_amp;
       }
-      if (tone_amp > 0) {
-        const uint64_t seg = n >> SYN_NOTE_SHIFT, m = n & ((1u << SYN_NOTE_SHIFT) - 1);
-        long long s = 0;
-#pragma unroll
-        for (int k = 0; k < SYN_NPART; ++k) {
-          uint64_t r = splitmix64(~key + seg * 8 + (uint64_t)k);
-          uint64_t om = (uint64_t)SYN_OM_MIN + (((r >> 32) * (uint64_t)(SYN_OM_MAX - SYN_OM_MIN)) >> 32);
-          uint32_t ph = (uint32_t)(r + m * om);
-          s += lut[ph >> 20];
-        }
-        acc += (s * tone_amp) >> 17;
-      }
+      if (tone_amp > 0) acc += tone[i];
       acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
       v[i] = (int16_t)acc;
     }
@@ -476,6 +512,7 @@ extern "C" int32_t shz_synth_pcm(shz_ctx* ctx, uint64_t seed, uint64_t clip0, ui
   if (tone_amp < 0 || noise_amp < 0 || tone_amp > 10000 || noise_amp > 32768)
     SHZ_FAIL(ctx, SHZ_E_INVALID, "shz_synth_pcm: tone_amp in [0,10000], noise_amp in [0,32768]");
   uint64_t per = (n_samples + 8 * 256 - 1) / (8 * 256);
+  per = tone_amp > 0 ? (per + 3) / 4 : per;   // (four strides a workgroup: the table is loaded into LDS once for them)
   dim3 grid((unsigned)(per > 4096 ? 4096 : per), n_clips);
   hipLaunchKernelGGL(synth_pcm_kernel, grid, dim3(256), 0, ctx->stream, dev_out, seed, clip0, n_samples, start_sample,
                      tone_amp, noise_amp, ctx->d_sine_lut);

@@ -58,12 +58,15 @@ def test_extraction_argument_errors(env):
     a = list(good)
     a[3] = 0
     assert _call(_ffi, "shz_fingerprint_batch", *a) == _ffi.OK and cnt.value == 0
-    # the Python API: a window the reference's specgram call rejects raises ValueError (mlab:242), other
-    # window sizes are not implemented on the HIP path
+    # the Python API: a window the reference's specgram call rejects raises ValueError (mlab:242); window sizes of 8192 and
+    # above and sizes that are not powers of two are not implemented on the HIP path
     with pytest.raises(ValueError):
         S.fingerprint(x, wsize=4096, wratio=1.0)
-    with pytest.raises(NotImplementedError):
-        S.fingerprint(x, wsize=2048)
+    with pytest.raises(ValueError):
+        S.fingerprint(x, wsize=1024, wratio=1.0)
+    for bad_size in (8192, 3000, 32):
+        with pytest.raises(NotImplementedError):
+            S.fingerprint(x, wsize=bad_size)
 
 
 def test_peaks_from_array_errors(env):
@@ -162,6 +165,17 @@ def test_round4_entry_points_refuse_bad_arguments(env):
     assert S.fingerprint(x) == before
     with pytest.raises(ValueError):
         S.fingerprint(x, wratio=-0.1)
+    # the generic spectrogram: NULL handle / buffers, capacity (reported through n_frames), no samples
+    xs = np.ascontiguousarray(x[:5000], np.int16)
+    out, nf = np.empty(257 * 18, np.float64), C.c_uint64()
+    assert L.shz_stft_db_any(None, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, _ffi.ptr(out), out.size, C.byref(nf)) == _ffi.E_INVALID
+    assert L.shz_stft_db_any(ctx.h, None, 5000, 44100, 512, 256, 0, _ffi.ptr(out), out.size, C.byref(nf)) == _ffi.E_INVALID
+    assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 0, 44100, 512, 256, 0, _ffi.ptr(out), out.size, C.byref(nf)) == _ffi.E_INVALID
+    assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 0, 512, 256, 0, _ffi.ptr(out), out.size, C.byref(nf)) == _ffi.E_INVALID
+    assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, _ffi.ptr(out), 100, C.byref(nf)) == _ffi.E_CAPACITY
+    assert nf.value == 18
+    assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, None, 0, C.byref(nf)) == _ffi.E_CAPACITY
+    assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, _ffi.ptr(out), out.size, None) == _ffi.OK
     # run rows: 0 (the limit of a sort) or >= 16
     tbl = S.Table(ctx)
     assert L.shz_table_set_run_rows(tbl.h, 5) == _ffi.E_INVALID and L.shz_table_set_run_rows(tbl.h, 0) == _ffi.OK

@@ -56,7 +56,8 @@ def _cases(golden_dir):
 
 def test_synth_matches_numpy_twin(ctx):
     from oracle import synth
-    for (ta, na, n, start) in ((0, 8000, 50001, 0), (4000, 1500, 70000, 0), (6000, 0, 40000, 12345), (0, 32768, 4099, 7)):
+    for (ta, na, n, start) in ((0, 8000, 50001, 0), (4000, 1500, 70000, 0), (6000, 0, 40000, 12345), (0, 32768, 4099, 7),
+                               (4000, 1500, 200003, 16381), (10000, 32768, 33000, 8), (1, 0, 9, 16383)):
         buf = ctx.synth_pcm(1234, 5, 3, n, ta, na, start)
         got = buf.download(np.int16, 3 * n).reshape(3, n)
         for c in range(3):
