@@ -1627,6 +1627,7 @@ __device__ __forceinline__ uint64_t vt_wave_max64(uint64_t v) {
   return ((uint64_t)h << 32) | l;
 }
 // counter of a (song | delta) key, 12 bits: the multiply is 24-bit (full rate); the bits above 24 are folded in first
+#define VW_SEED_TILES 16u      // tiles at the head of a query that fold undecided batches on the spot (vt_stream2_kernel)
 #define VW_FILTER_MAX 200u     // a counter that gets here sends its batch to the exact fold whatever the bar (8 bits wrap at 256)
 __device__ __forceinline__ uint32_t vw_hash_filter(uint32_t x) { return (__umul24((x ^ (x >> 13)) & 0xFFFFFFu, 0x9E3779u) >> 11) & 4095u; }
 static_assert(VW_S1 * 8 == 4096, "table 1 (keys + counts) is 4 KB: 4,096 eight-bit counters");
@@ -1763,44 +1764,76 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     unsigned long long hit = 0;                      // wave-uniform: lanes whose counter reached the bar in this batch
     uint32_t cm = 0;                                 // per lane: the largest counter value it saw in this batch
     uint32_t cur_hi = 0;                             // the ordered bits of the batch's first vote
-    uint32_t thr = 2u;                               // a counter at or above this sends the batch to the exact fold
+    uint32_t thr = 2u;                               // a counter at or above this marks the batch (`hit`)
+    uint32_t thr1 = 0u;                              // the count a pair of the batch needs to get past the bar (0: anything does)
     uint64_t own = 0;                                // the tile's n-th candidate (0: the list is not full)
     const int slb = pl.g_lo - 1 - pl.dbits;          // bits of a song id below the ordered ones: song id >= (hi << slb)
-    auto set_thr = [&](uint32_t first_hi) {          // first_hi: the ordered bits of the batch's first vote
-      cur_hi = first_hi;
-      own = nth_own();
-      const uint64_t bar = own > bar_q ? own : bar_q;
+    // the smallest count that lets a pair of a batch whose lowest possible id is first_hi << slb past `bar`
+    auto thr_of = [&](uint64_t bar, uint32_t first_hi) -> uint32_t {
       uint32_t barc = (uint32_t)(bar >> 32);
       // a pair that only EQUALS the bar's count wins on the smaller song id: never, when every id of the batch (ids ascend
       // along a tile, and tile after tile) lies above the bar's song -- then a counter must EXCEED the bar's count
       const uint32_t bar_sid = 0xFFFFFFFFu - (uint32_t)bar;
       if (barc != 0u && ((uint64_t)first_hi << slb) > (uint64_t)bar_sid) ++barc;
-      thr = barc < 2u ? 2u : (barc > VW_FILTER_MAX ? VW_FILTER_MAX : barc);   // (count 1 is not the filter's business: see end_batch)
+      return barc;
+    };
+    auto set_thr = [&](uint32_t first_hi) {          // first_hi: the ordered bits of the batch's first vote
+      cur_hi = first_hi;
+      own = nth_own();
+      thr1 = thr_of(own > bar_q ? own : bar_q, first_hi);
+      thr = thr1 < 2u ? 2u : (thr1 > VW_FILTER_MAX ? VW_FILTER_MAX : thr1);   // (count 1 is not the filter's business: thr1 < 2 is)
+    };
+    auto refresh_bar = [&]() {                       // the query's bar as it stands now
+      unsigned long long now = 0;
+      if (lane == 0) now = __hip_atomic_load(&qbar[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      now = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(now >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)now);
+      if (now > bar_q) bar_q = now;
+    };
+    // does a batch whose largest counter was cmax (>= 1: every vote is a pair of count 1) still need the exact fold, with
+    // the tile's list and the query's bar as they are NOW?  (Exact batches of a tile run in ascending order of ids, so the
+    // tile's own candidates come from lower ids than the batch's.)
+    auto needed = [&](uint32_t cmax, uint32_t first_hi) -> bool {
+      own = nth_own();
+      return cmax >= VW_FILTER_MAX || cmax >= thr_of(own > bar_q ? own : bar_q, first_hi);
+    };
+    // DEFERRED batches.  All tiles of a query start together with no bar at all, and a bar worth having (count 2 at a low
+    // id, which makes every later batch need count 3) only exists once a few tiles have folded a few batches exactly; a tile
+    // that decided every batch on the spot paid one exact fold for its first batch (no bar) and more for the counter
+    // collisions of the next ones (count-1 bar) -- 60 % of the time of a single query's fold (measured with the bar left
+    // over from the previous call: 0.345 -> 0.283 ms a query at 1M songs).  So only the query's first VW_SEED_TILES tiles
+    // (the lowest ids: their bars are the ones that bind everybody else) decide on the spot; the others note an undecided
+    // batch -- its range, first ordered bits and largest counter, in the registers of lane i for note i -- and decide
+    // when the tile's stream has ended (or 64 notes are there), in order, against the bar of that moment.
+    const bool seed_tile = g - pl.tb[qi] < VW_SEED_TILES;
+    uint32_t npend = 0;                              // wave-uniform
+    uint32_t pd_s = 0, pd_e = 0, pd_hi = 0, pd_c = 0;   // lane i: note i
+    auto run_pending = [&]() {
+      if (npend == 0) return;
+      refresh_bar();
+      for (uint32_t i = 0; i < npend; ++i) {         // uniform
+        const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)pd_s, (int)i), pe = (uint32_t)__builtin_amdgcn_readlane((int)pd_e, (int)i);
+        const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)pd_hi, (int)i), pc = (uint32_t)__builtin_amdgcn_readlane((int)pd_c, (int)i);
+        if (needed(pc, ph)) { ++st_beat; st_votes_redo += pe - ps; exact_batch(ps, pe); }   // (which looks at the bar again)
+      }
+      npend = 0;
     };
     auto end_batch = [&](uint32_t e, uint32_t next_hi) {   // next_hi: the ordered bits of the vote at e (the next batch's first)
       ++st_b;
-      bool redo = hit != 0ull;
-      if (redo) {
-        // the query's bar has risen since this tile last looked (all tiles of a query start together, with no bar at all):
-        // look again before paying for the exact fold -- the lanes' largest counters are tested against the new threshold
-        unsigned long long now = 0;
-        if (lane == 0) now = __hip_atomic_load(&qbar[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        now = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(now >> 32)) << 32) |
-              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)now);
-        if (now > bar_q) {
-          bar_q = now;
-          set_thr(cur_hi);
-          redo = __ballot(cm >= thr) != 0ull;
+      bool fold_now = false;
+      if (hit != 0ull || thr1 < 2u) {                // a counter reached the batch's threshold, or songs of count 1 may still enter
+        const uint32_t w = vt_wave_max(cm), cmax = w < 1u ? 1u : w;
+        if (seed_tile) {
+          if (hit != 0ull) refresh_bar();            // (it has risen since the batch began, more often than not)
+          fold_now = needed(cmax, cur_hi);
+        } else {
+          ++st_seed;
+          if (npend == 64u) { clear_filter(); run_pending(); }
+          if (lane == npend) { pd_s = batch_start; pd_e = e; pd_hi = cur_hi; pd_c = cmax; }
+          ++npend;
         }
       }
-      st_beat += redo;
-      if (!redo && (own > bar_q ? own : bar_q) < (2ull << 32)) {
-        // no pair of the batch has a second vote, and songs of count 1 may still enter: not below the tile's OWN earlier
-        // batches (ids ascend inside a tile), but below another tile's count-1 bar they may
-        redo = own == 0 || bar_q > own;
-        st_seed += redo;
-      }
-      if (redo) { st_votes_redo += e - batch_start; exact_batch(batch_start, e); }
+      if (fold_now) { ++st_beat; st_votes_redo += e - batch_start; exact_batch(batch_start, e); }
       else clear_filter();
       set_thr(next_hi);
       hit = 0ull;
@@ -1876,6 +1909,7 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     }
     consume();
     end_batch(b, 0xFFFFFFFFu);
+    run_pending();
     if (stats && lane == 0) {
       atomicAdd(stats + 0, (unsigned long long)st_b);
       atomicAdd(stats + 2, (unsigned long long)st_seed); atomicAdd(stats + 3, (unsigned long long)st_beat);
@@ -2106,8 +2140,9 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_VT6, 8ull * (VT_MAXQ + 1), &p));
     d_qbar = (unsigned long long*)p;
   }
+  static const bool keep_bar = [] { const char* e = getenv("SHZ_VT_KEEPBAR"); return e && atoi(e) != 0; }();   // EXPERIMENT
   hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)std::max<uint32_t>(nt, VT_MAXQ) + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start,
-                     n_heavy, d_qbar);
+                     n_heavy, keep_bar ? nullptr : d_qbar);
   // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
   const int slb_ = pl.g_lo - 1 - mbp.dbits;
   const double per_song = std::max(1.0, (double)pp / nqp / std::max<uint32_t>(max_sid, 1u));
