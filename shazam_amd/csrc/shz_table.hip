@@ -323,8 +323,10 @@ __global__ void m_compact_idx_kernel(const uint32_t* __restrict__ flag, const ui
 __global__ void m_probe_kernel(const uint64_t* __restrict__ E, const uint32_t* __restrict__ gs,
                                const unsigned long long* __restrict__ ng_dev, uint64_t bound,
                                const shz_seg_dev* __restrict__ segs, uint32_t nseg, uint32_t* __restrict__ g_lo,
-                               uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total) {
+                               uint64_t* __restrict__ g_pairs, unsigned long long* __restrict__ rows_total,
+                               uint32_t* __restrict__ rb, uint32_t rb_words) {
   const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t i = x; i < rb_words; i += (uint64_t)gridDim.x * blockDim.x) rb[i] = 0u;   // the result block (a fill launch otherwise)
   const uint64_t nx = (uint64_t)*ng_dev * nseg;   // <= bound - 1: slots past nx count no pairs
   unsigned long long s = 0;
   if (x < nx) {
@@ -1106,24 +1108,41 @@ __device__ __forceinline__ uint32_t vt_query_of_tile(const vt_plan& pl, uint32_t
 }
 
 // tile_start[g], g = 0 .. ntiles: the first tile of a query starts at the query's first vote, the others at the first
-// group border at or behind their nominal start (binary search: the votes are ordered by the bits >= g_lo)
-__global__ void vt_bounds_kernel(const uint32_t* __restrict__ k, vt_plan pl, uint32_t* __restrict__ tile_start,
-                                 uint32_t* __restrict__ n_heavy, unsigned long long* __restrict__ qbar) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, nt = pl.tb[pl.nq];
-  if (qbar && g <= VT_MAXQ) qbar[g] = 0ull;          // the queries' bars start at nothing (vt_stream2_kernel)
+// group border at or behind their nominal start.  One WAVE per tile: the border is a few dozen votes away as a rule (a
+// group is 2^slb songs), so the wave looks at the next 63 votes at once, then at three more rows, and only a group longer
+// than that is searched by halving (the votes are ordered by the bits >= g_lo) -- one or two dependent loads instead of the
+// ~23 of a binary search over the whole query, which was 10 us of a single query's 300.
+__global__ __launch_bounds__(256) void vt_bounds_kernel(const uint32_t* __restrict__ k, vt_plan pl, uint32_t* __restrict__ tile_start,
+                                                        uint32_t* __restrict__ n_heavy, unsigned long long* __restrict__ qbar) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = pl.tb[pl.nq];
+  if (qbar && t <= VT_MAXQ) qbar[t] = 0ull;          // the queries' bars start at nothing (vt_stream2_kernel)
+  const uint32_t g = t >> 6, lane = t & 63u;
   if (g > nt) return;
-  if (g == nt) { tile_start[g] = pl.qv[pl.nq]; *n_heavy = 0; return; }
+  if (g == nt) { if (lane == 0) { tile_start[g] = pl.qv[pl.nq]; *n_heavy = 0; } return; }
   const uint32_t i = vt_query_of_tile(pl, g), l = g - pl.tb[i];
   const uint32_t a = pl.qv[i], b = pl.qv[i + 1];
-  if (l == 0) { tile_start[g] = a; return; }
+  if (l == 0) { if (lane == 0) tile_start[g] = a; return; }
   const uint32_t p = a + l * pl.tile;   // < b: the query has ceil((b - a) / tile) tiles
-  const uint32_t h = k[p - 1] >> pl.g_lo;
-  uint32_t lo = p, hi = b;              // first position in [p, b) whose upper bits exceed h
-  while (lo < hi) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    if ((k[mid] >> pl.g_lo) > h) hi = mid; else lo = mid + 1;
+  uint32_t pos = p - 1, found = b;      // lane 0 of the first row holds the vote in front of the nominal start
+  uint32_t h = 0;
+  bool done = false;
+  for (int r = 0; r < 4 && pos < b; ++r) {           // uniform
+    const uint32_t j = pos + lane;
+    const uint32_t v = j < b ? k[j] >> pl.g_lo : 0u;
+    if (r == 0) h = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    const unsigned long long m = __ballot(j < b && v > h);   // (lane 0 of the first row is the vote itself: not above itself)
+    if (m) { found = pos + (uint32_t)__ffsll((long long)m) - 1; done = true; break; }
+    pos += 64;
   }
-  tile_start[g] = lo;
+  if (!done && pos < b) {
+    uint32_t lo = pos, hi = b;          // first position in [pos, b) whose upper bits exceed h
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if ((k[mid] >> pl.g_lo) > h) hi = mid; else lo = mid + 1;
+    }
+    found = lo;
+  }
+  if (lane == 0) tile_start[g] = found;
 }
 
 #define VT_SLOTS2 4096         // table 2 (one entry per song)
@@ -2141,7 +2160,7 @@ static int32_t vt_run_pass(shz_ctx* ctx, uint32_t* k32, uint32_t* k32_alt, uint6
     d_qbar = (unsigned long long*)p;
   }
   static const bool keep_bar = [] { const char* e = getenv("SHZ_VT_KEEPBAR"); return e && atoi(e) != 0; }();   // EXPERIMENT
-  hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk((uint64_t)std::max<uint32_t>(nt, VT_MAXQ) + 1)), dim3(256), 0, ctx->stream, ks, pl, tile_start,
+  hipLaunchKernelGGL(vt_bounds_kernel, dim3(nblk(std::max<uint64_t>(((uint64_t)nt + 1) * 64, (uint64_t)VT_MAXQ + 1))), dim3(256), 0, ctx->stream, ks, pl, tile_start,
                      n_heavy, keep_bar ? nullptr : d_qbar);
   // songs a batch is expected to hold: the 2^slb ids of a group + the ids that fill 64 votes
   const int slb_ = pl.g_lo - 1 - mbp.dbits;
@@ -2361,17 +2380,17 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
     hipLaunchKernelGGL(m_compact_idx_kernel, dim3(nblk(m)), dim3(256), 0, ctx->stream, (const uint32_t*)fl,
                        (const uint32_t*)ps, &d_ctl->mu, m, &d_ctl->ng, (uint32_t*)gs);
     }
-    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx_bound)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
-                       (const uint32_t*)gs, &d_ctl->ng, nx_bound, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
-                       (uint64_t*)gpairs, (unsigned long long*)ctl_p + 16);
-    SHZ_HIP(ctx, hipGetLastError());
-    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx_bound, tot + 3));
-    // results and per-query counters in ONE device block: one fill before, one copy after.
+    // results and per-query counters in ONE device block: zeroed by the probe, one copy after.
     // layout: npairs[nq] u64 | sid, delta, aligned, dedup [nq * topn] u32 each | nres[nq] | nhash[nq]
     const uint64_t nres = (uint64_t)nq * (vs_out ? 0 : topn);
     const uint64_t rb_bytes = (uint64_t)nq * 8 + nres * 16 + (uint64_t)nq * 8 + 8;   // + the vote tiles' flag word (and a pad)
     void* rb;
     SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PEAK_F, rb_bytes + 64, &rb));
+    hipLaunchKernelGGL(m_probe_kernel, dim3(nblk(nx_bound)), dim3(256), 0, ctx->stream, (const uint64_t*)E,
+                       (const uint32_t*)gs, &d_ctl->ng, nx_bound, (const shz_seg_dev*)d_segs, (uint32_t)nseg, (uint32_t*)glo,
+                       (uint64_t*)gpairs, (unsigned long long*)ctl_p + 16, (uint32_t*)rb, (uint32_t)((rb_bytes + 3) / 4));
+    SHZ_HIP(ctx, hipGetLastError());
+    SHZ_TRY(shz_scan_u64(ctx, (const uint64_t*)gpairs, (uint64_t*)po, nx_bound, tot + 3));
     uint64_t* d_np = (uint64_t*)rb;
     uint32_t* r_sid = (uint32_t*)(d_np + nq);
     uint32_t *r_delta = r_sid + nres, *r_al = r_delta + nres, *r_dd = r_al + nres, *r_n = r_dd + nres, *d_nh = r_n + nq;
@@ -2434,8 +2453,6 @@ static int32_t match_core(shz_ctx* ctx, shz_table* t, const uint32_t* key32, con
         SHZ_HIP(ctx, hipGetLastError());
       }
     }
-    // (a queued query's first kernel did that; whole 64-byte lines: the runtime fills a ragged size in two launches)
-    if (!spec) SHZ_HIP(ctx, hipMemsetAsync(rb, 0, (rb_bytes + 63) & ~63ull, ctx->stream));
     if (nq > 1) {   // one query: its counts are the totals
       hipLaunchKernelGGL(m_query_stats_kernel, dim3(nblk(nq)), dim3(256), 0, ctx->stream, (const uint64_t*)E, (const mctl*)d_ctl,
                          (const uint32_t*)gs, (const uint64_t*)po, (uint32_t)nseg, nq, d_nh, d_np);
