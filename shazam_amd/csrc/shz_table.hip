@@ -117,8 +117,8 @@ __device__ __forceinline__ uint32_t mh_block_scan(uint32_t v, uint32_t* total, u
 // Stable LSD radix sort of m <= MH_MAX keys that sit in sk[0], on bits [bit_lo, bit_hi), 8 bits per pass, all in LDS.
 // Wave w owns the slice [w * 64 rows, (w + 1) * 64 rows), rows = ceil(m / 1024): every pass ranks a slice's elements among themselves by ballots
 // (the scheme of sort_scatter_kernel), prefixes the per-wave digit counts over the waves and the digits, and scatters
-// into the other buffer.  Passes over digits on which no two keys differ (`diff` = OR of all keys ^ AND of all keys)
-// are skipped.  Returns the index of the buffer that holds the result.  Ends with a barrier.
+// into the other buffer.  Bits on which no two keys differ (`diff` = OR of all keys ^ AND of all keys) are skipped: a
+// digit begins at the next differing bit.  Returns the index of the buffer that holds the result.  Ends with a barrier.
 __device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wrun)[256], uint32_t* dbase, uint32_t m,
                                            int bit_lo, int bit_hi, unsigned long long diff) {
   const int rows = (int)((m + MH_THREADS - 1) / MH_THREADS);   // rows of 64 elements per wave: the slices shrink with m
@@ -126,8 +126,13 @@ __device__ __forceinline__ int mh_lds_sort(uint64_t (*sk)[MH_MAX], uint16_t (*wr
   const unsigned long long lt = (1ull << lane) - 1ull;
   int cur = 0;
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    // a digit starts at the next bit on which any two keys differ (not at a multiple of 8): offsets of 8 bits + 32 key bits
+    // are five passes wherever the fields sit, not six
+    const unsigned long long rest = shift < 64 ? diff >> shift : 0ull;
+    if (rest == 0ull) break;                        // uniform
+    shift += __ffsll((long long)rest) - 1;
+    if (shift >= bit_hi) break;
     const uint32_t dmask = (1u << min(8, bit_hi - shift)) - 1u;
-    if (((diff >> shift) & dmask) == 0) continue;   // uniform
     for (int i = j; i < (MH_THREADS / 64) * 256; i += MH_THREADS) (&wrun[0][0])[i] = 0;
     __syncthreads();
     uint64_t k[MH_ROWS];
@@ -1850,6 +1855,9 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
           if (npend == 64u) { clear_filter(); run_pending(); }
           if (lane == npend) { pd_s = batch_start; pd_e = e; pd_hi = cur_hi; pd_c = cmax; }
           ++npend;
+          // a tile that keeps noting batches has a stale bar (none, if it started with its query): look again now and then
+          // -- with a bar worth having, notes become rare and so do these loads
+          if ((npend & 7u) == 0u) refresh_bar();
         }
       }
       if (fold_now) { ++st_beat; st_votes_redo += e - batch_start; exact_batch(batch_start, e); }
@@ -1882,7 +1890,10 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     // the next VW_AHEAD rows of votes: loads in flight.  The wave waits for memory, not for issue slots (SQ counters: 90 % of
     // its cycles) -- 26 waves a CU with 4 rows each in flight are 6.8 MB on the whole chip, what ~3 us of loaded latency
     // turn into ~2 TB/s at best
-    constexpr int VW_AHEAD = 8;
+#ifndef VW_AHEAD_N
+#define VW_AHEAD_N 8
+#endif
+    constexpr int VW_AHEAD = VW_AHEAD_N;
     uint32_t rr[VW_AHEAD];
 #pragma unroll
     for (int j = 0; j < VW_AHEAD; ++j) { const uint32_t i = a + lane + 64u * j; rr[j] = i < b ? k[i] : 0u; }
