@@ -196,6 +196,11 @@ int32_t shz_upload_stats(shz_ctx* ctx, uint64_t* chunks, uint64_t* bytes, double
  * noverlap >= 4096: SHZ_E_INVALID (mlab raises ValueError, mlab:242).  Other wsize: not implemented -- the Python layer raises
  * NotImplementedError, there is no CPU fallback. */
 int32_t shz_set_overlap(shz_ctx* ctx, uint32_t noverlap);
+/* numpy's tables for a window of nfft samples, as the fp64 path uses them (no GPU needed; any argument may be NULL):
+ * window[nfft] = np.hanning(nfft) (mlab.window_hanning), twiddles[2 nfft] = (re, im) of the values pocketfft's
+ * sincos_2pibyn(nfft) holds (cos, +sin of 2 pi i / nfft: the forward passes conjugate), *sumsq = (window ** 2).sum() in
+ * numpy's pairwise order.  For tests: tests/test_numpy_tables.py compares them with numpy's own bits on the host. */
+int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double* sumsq);
 /* mlab.specgram(x, NFFT=nfft, Fs, window_hanning, noverlap)[0] -> 10*log10 where != 0 (__init__.py:232-241) for window sizes
  * OTHER than 4096: nfft a power of two in [64, 2048].  A generic kernel (one workgroup per frame, radix-2 in fp64) -- correct,
  * not fast; the reference and every caller of it use 4096.  pcm: host, one channel; out_db: host [nfft/2 + 1][n_frames]

@@ -51,6 +51,7 @@ SIGNATURES = {
     "shz_frame_count": (C.c_uint32, [C.c_uint64]),
     "shz_frame_count_hop": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "shz_set_overlap": (C.c_int32, [vp, C.c_uint32]),
+    "shz_numpy_tables": (C.c_int32, [C.c_uint32, vp, vp, vp]),
     "shz_stft_db_any": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),

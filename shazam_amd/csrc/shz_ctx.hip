@@ -147,6 +147,98 @@ hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
   return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------------------
+// numpy's tables, for the fp64 path that follows the reference's arithmetic operation by operation (mlab._spectral_helper
+// -> np.fft.fft, the call of __init__.py:232-237).  Nothing of this is in /root/reference: numpy (2.x) computes a complex
+// FFT with the C++ pocketfft, whose plan for n = 4096 is four radix-8 passes with twiddles from `sincos_2pibyn`: two short
+// tables of cos / sin (libm, double) whose entries are multiplied -- restated here from the published algorithm and pinned
+// by tests/test_numpy_tables.py, which compares the tables and a transform built on them with numpy's own bits.
+//   window   np.hanning(n): 0.5 + 0.5 cos(pi k / (n - 1)), k = 1 - n, 3 - n, ...        (mlab.window_hanning)
+//   comp[i]  exp(-2 pi i / n) ... the value pocketfft's comp[i] holds (cos, +sin of 2 pi i / n; the passes conjugate)
+//   sumsq    (window ** 2).sum() in numpy's pairwise order (8 running sums per block of <= 128, halves above)
+static void np_sc_calc(size_t x, size_t n, double ang, double* re, double* im) {
+  x <<= 3;
+  if (x < 4 * n) {
+    if (x < 2 * n) {
+      if (x < n) { *re = cos((double)x * ang); *im = sin((double)x * ang); return; }
+      *re = sin((double)(2 * n - x) * ang); *im = cos((double)(2 * n - x) * ang); return;
+    }
+    x -= 2 * n;
+    if (x < n) { *re = -sin((double)x * ang); *im = cos((double)x * ang); return; }
+    *re = -cos((double)(2 * n - x) * ang); *im = sin((double)(2 * n - x) * ang); return;
+  }
+  x = 8 * n - x;
+  if (x < 2 * n) {
+    if (x < n) { *re = cos((double)x * ang); *im = -sin((double)x * ang); return; }
+    *re = sin((double)(2 * n - x) * ang); *im = -cos((double)(2 * n - x) * ang); return;
+  }
+  x -= 2 * n;
+  if (x < n) { *re = -sin((double)x * ang); *im = -cos((double)x * ang); return; }
+  *re = -cos((double)(2 * n - x) * ang); *im = -sin((double)(2 * n - x) * ang);
+}
+
+static double np_pairwise_sum(const double* a, size_t n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (size_t i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    size_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  size_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+void shz_numpy_tables_host(uint32_t n, double* window, double2* comp, double* sumsq) {
+  if (window) {
+    std::vector<double> sq(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      const double k = (double)(1 - (long)n + 2 * (long)i);
+      window[i] = n > 1 ? 0.5 + 0.5 * cos(M_PI * k / (double)(n - 1)) : 1.0;
+      sq[i] = window[i] * window[i];
+    }
+    if (sumsq) *sumsq = np_pairwise_sum(sq.data(), n);
+  }
+  if (comp) {
+    const long double pi = 3.141592653589793238462643383279502884197L;
+    const double ang = (double)(0.25L * pi / (long double)n);
+    const size_t nval = ((size_t)n + 2) / 2;
+    size_t shift = 1;
+    while (((size_t)1 << shift) * ((size_t)1 << shift) < nval) ++shift;
+    const size_t mask = ((size_t)1 << shift) - 1;
+    std::vector<double2> v1(mask + 1), v2((nval + mask) / (mask + 1));
+    v1[0] = double2{1.0, 0.0};
+    for (size_t i = 1; i < v1.size(); ++i) np_sc_calc(i, n, ang, &v1[i].x, &v1[i].y);
+    v2[0] = double2{1.0, 0.0};
+    for (size_t i = 1; i < v2.size(); ++i) np_sc_calc(i * (mask + 1), n, ang, &v2[i].x, &v2[i].y);
+    for (size_t idx = 0; idx < n; ++idx) {
+      if (2 * idx <= n) {
+        const double2 x1 = v1[idx & mask], x2 = v2[idx >> shift];
+        comp[idx] = double2{x1.x * x2.x - x1.y * x2.y, x1.x * x2.y + x1.y * x2.x};
+      } else {
+        const size_t m = n - idx;
+        const double2 x1 = v1[m & mask], x2 = v2[m >> shift];
+        comp[idx] = double2{x1.x * x2.x - x1.y * x2.y, -(x1.x * x2.y + x1.y * x2.x)};
+      }
+    }
+  }
+}
+
+extern "C" int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double* sumsq) {
+  if (nfft < 2 || nfft > (1u << 20)) return SHZ_E_INVALID;
+  shz_numpy_tables_host(nfft, window, (double2*)twiddles, sumsq);
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
   if (!out) return SHZ_E_INVALID;
   *out = nullptr;
@@ -186,7 +278,14 @@ extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
     for (int k = 0; k < 64; ++k) tw.push_back(W(8L * k * t));
   std::vector<int16_t> lut(4096);
   for (int i = 0; i < 4096; ++i) lut[i] = (int16_t)lrint(32767.0 * sin(2.0 * M_PI * (double)i / 4096.0));
-  bool ok = hipMalloc(&ctx->d_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&
+  std::vector<double> npw(SHZ_NFFT);
+  std::vector<double2> npc(SHZ_NFFT);
+  shz_numpy_tables_host(SHZ_NFFT, npw.data(), npc.data(), &ctx->np_sumsq);
+  bool ok = hipMalloc(&ctx->d_np_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&
+            hipMalloc(&ctx->d_np_comp, sizeof(double2) * SHZ_NFFT) == hipSuccess &&
+            hipMemcpy(ctx->d_np_window, npw.data(), sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(ctx->d_np_comp, npc.data(), sizeof(double2) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&ctx->d_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&
             hipMalloc(&ctx->d_twiddle, sizeof(double2) * tw.size()) == hipSuccess &&
             hipMalloc(&ctx->d_sine_lut, sizeof(int16_t) * 4096) == hipSuccess &&
             hipMemcpy(ctx->d_window, win.data(), sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&
@@ -210,6 +309,8 @@ extern "C" int32_t shz_ctx_destroy(shz_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   ctx->blocks.clear();
   if (ctx->d_window) (void)hipFree(ctx->d_window);
+  if (ctx->d_np_window) (void)hipFree(ctx->d_np_window);
+  if (ctx->d_np_comp) (void)hipFree(ctx->d_np_comp);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_sine_lut) (void)hipFree(ctx->d_sine_lut);
   if (ctx->twin) { (void)shz_ctx_destroy(ctx->twin); ctx->twin = nullptr; }

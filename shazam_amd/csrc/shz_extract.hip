@@ -82,6 +82,10 @@ struct stft_args {
   double scale;                // 0.25 / (Fs * sum(w^2))
   uint32_t opt;                // experiment switches (SHZ_STFT_OPT): 1 = no rotation of the special wave, 2 = one frame loop for all waves
   uint32_t hop;                // new samples per frame = NFFT - noverlap (mlab:307-308); 2,048 unless shz_set_overlap says otherwise
+  // numpy's arithmetic (stft_np_kernel, peak_verify_kernel): np.hanning(4096), pocketfft's twiddles, 1 / Fs, 1 / sum(w^2)
+  const double* np_window;
+  const cplx* np_comp;
+  double r_fs, r_s;
 };
 
 // The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
@@ -344,6 +348,128 @@ __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, doubl
   // (a wave-uniform branch around this call alone was tried: everything live in the frame crosses the split, 76 spilled
   // registers against 16 -- the kernel branches once, outside the frame loop, instead)
   stft_p4_rest<SPECIAL>(v, T, j, scale, before_out, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// THE REFERENCE'S OWN ARITHMETIC, operation by operation (round 4).  Where a decision hangs on the last bits of a power --
+// fp64 staging (clips fp32 cannot decide, whole passes with amp_min < 0, shz_stft_db) and the cells peak_verify_kernel
+// recomputes -- the power is computed the way the call of __init__.py:232-237 computes it on a host with numpy 2.x:
+//   result = x[frame] * np.hanning(4096)                  one product a sample
+//   np.fft.fft(result)                                    pocketfft's COMPLEX transform of the real frame: for 4096 = 8^4
+//                                                         four radix-8 passes (its `pass8`), twiddles from `sincos_2pibyn`,
+//                                                         no fused multiply-add anywhere
+//   np.conj(result) * result                              real part = fma(re, re, im * im): numpy's complex product on a
+//                                                         host with FMA3 (x86-64 AVX2 / AVX-512: `npyv_muladdsub`)
+//   result[1:-1] *= 2; result /= Fs; result /= (w**2).sum()   the two divisions are complex / real: numpy multiplies by
+//                                                         the rounded reciprocals 1.0 / Fs and 1.0 / sum
+// numpy and pocketfft are third-party code that is not in /root/reference; the passes below restate the
+// published algorithm and are pinned by digests of the reference's own spectrograms (tests/golden/psd_digests.json, all
+// 1.3 M values of a 30 s clip bit for bit) and by the click-train fixture, whose 1,519 peaks hang on exactly these bits.
+// The dataflow of a pass is pocketfft's (butterfly (k, i) of pass p reads cc[i + ido (b + 8 k)], b = 0..7, and writes
+// ch[i + ido (k + l1 c)], c = 0..7, times comp[c l1 i] for i > 0); the array lives in ONE LDS buffer (all reads of a pass,
+// barrier, all writes).  Built for correctness: ~2x the time of stft_psd_kernel, and only ever run on what fp32 left open.
+__device__ __forceinline__ cplx np_smul(cplx v, cplx w) {   // special_mul<fwd>: v * conj(w), products and sums rounded one by one
+  return make_double2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+}
+__device__ __forceinline__ void np_bfly8(const cplx (&c)[8], cplx (&o)[8]) {
+  const double hsqt2 = 0.707106781186547524400844362104849;
+  cplx a0, a1, a2, a3, a4, a5, a6, a7;
+  a1 = cadd(c[1], c[5]); a5 = csub(c[1], c[5]);                       // PM(a1, a5, c1, c5)
+  a3 = cadd(c[3], c[7]); a7 = csub(c[3], c[7]);                       // PM(a3, a7, c3, c7)
+  { const cplx t = a1; a1 = cadd(a1, a3); a3 = csub(t, a3); }         // PMINPLACE(a1, a3)
+  a3 = make_double2(a3.y, -a3.x);                                     // ROTX90<fwd>(a3)
+  a7 = make_double2(a7.y, -a7.x);                                     // ROTX90<fwd>(a7)
+  { const cplx t = a5; a5 = cadd(a5, a7); a7 = csub(t, a7); }         // PMINPLACE(a5, a7)
+  a5 = make_double2(hsqt2 * (a5.x + a5.y), hsqt2 * (a5.y - a5.x));    // ROTX45<fwd>(a5)
+  a7 = make_double2(hsqt2 * (a7.y - a7.x), hsqt2 * (-a7.x - a7.y));   // ROTX135<fwd>(a7)
+  a0 = cadd(c[0], c[4]); a4 = csub(c[0], c[4]);                       // PM(a0, a4, c0, c4)
+  a2 = cadd(c[2], c[6]); a6 = csub(c[2], c[6]);                       // PM(a2, a6, c2, c6)
+  { const cplx t = a0; a0 = cadd(a0, a2); a2 = csub(t, a2); }         // PMINPLACE(a0, a2)
+  o[0] = cadd(a0, a1); o[4] = csub(a0, a1);
+  o[2] = cadd(a2, a3); o[6] = csub(a2, a3);
+  a6 = make_double2(a6.y, -a6.x);                                     // ROTX90<fwd>(a6)
+  { const cplx t = a4; a4 = cadd(a4, a6); a6 = csub(t, a6); }         // PMINPLACE(a4, a6)
+  o[1] = cadd(a4, a5); o[5] = csub(a4, a5);
+  o[3] = cadd(a6, a7); o[7] = csub(a6, a7);
+}
+// buf: the 4096 complex inputs in natural order; 256 threads; the caller has put a barrier behind its stores.  Returns with
+// the transform in buf, natural order, behind a barrier.
+__device__ __forceinline__ void np_fft4096(cplx* buf, const cplx* __restrict__ comp, int j) {
+#pragma unroll 1
+  for (int p = 0; p < 4; ++p) {
+    const int ls = 3 * p, is = 9 - 3 * p;             // l1 = 8^p butterflies groups, ido = 512 / 8^p
+    const int ido = 1 << is;
+    cplx o[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bf = j + 256 * u, k = bf >> is, i = bf & (ido - 1);
+      cplx c[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) c[b] = buf[i + ((b + 8 * k) << is)];
+      np_bfly8(c, o[u]);
+      if (i != 0) {
+#pragma unroll
+        for (int cc = 1; cc < 8; ++cc) o[u][cc] = np_smul(o[u][cc], comp[(cc * i) << ls]);
+      }
+    }
+    __syncthreads();   // every butterfly holds its inputs
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bf = j + 256 * u, k = bf >> is, i = bf & (ido - 1);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) buf[i + ((k + (cc << ls)) << is)] = o[u][cc];
+    }
+    __syncthreads();
+  }
+}
+// power of bin k from its transform value, scaled as mlab scales it
+__device__ __forceinline__ double np_power(cplx X, int k, double r_fs, double r_s) {
+  double p = fma(X.x, X.x, X.y * X.y);
+  if (k != 0 && k != SHZ_NFFT / 2) p *= 2.0;
+  p = p * r_fs;
+  return p * r_s;
+}
+// windowed samples of a frame into buf (real parts; thread j holds samples 2n, 2n + 1, n = j + 256 t)
+__device__ __forceinline__ void np_stage_frame(cplx* buf, const int (&pw)[8], const double2 (&ww)[8], int j) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int n = j + 256 * t;
+    *reinterpret_cast<double4*>(&buf[2 * n]) = make_double4((double)(short)(pw[t] & 0xFFFF) * ww[t].x, 0.0, (double)(pw[t] >> 16) * ww[t].y, 0.0);
+  }
+}
+
+#define NP_FRAMES_PER_WG 8
+__global__ __launch_bounds__(256) void stft_np_kernel(stft_args a) {
+  __shared__ cplx buf[SHZ_NFFT];
+  const int j = threadIdx.x;
+  double2 ww[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.np_window + 2 * (j + 256 * t));
+  const uint32_t g0 = blockIdx.x * NP_FRAMES_PER_WG, gend = min(g0 + NP_FRAMES_PER_WG, a.total_frames);
+  uint32_t lo = 0;
+  for (uint32_t g = g0; g < gend; ++g) {
+    if (g == g0) {
+      uint32_t hi = a.n_clips;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.clip_foff[mid] <= g) lo = mid; else hi = mid;
+      }
+    } else {
+      while (lo + 1 < a.n_clips && a.clip_foff[lo + 1] <= g) ++lo;
+    }
+    int pw[8];
+    stft_load_frame(a, lo, g, j, pw);
+    np_stage_frame(buf, pw, ww, j);
+    __syncthreads();
+    np_fft4096(buf, a.np_comp, j);
+    double* orow = reinterpret_cast<double*>(a.out) + (uint64_t)g * DB_STRIDE;
+#pragma unroll
+    for (int t = 0; t <= 8; ++t) {
+      const int k = j + 256 * t;
+      if (k <= SHZ_NFFT / 2) orow[k] = stage_value<double>(np_power(buf[k], k, a.r_fs, a.r_s));
+    }
+    __syncthreads();   // buf is rewritten by the next frame
+  }
 }
 
 #define P32_STRIDE 2064  // floats per fp32 row: 2049 bins padded so every row starts 64-byte aligned
@@ -1219,6 +1345,10 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.hop = ctx->hop;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
+  a.np_window = ctx->d_np_window;
+  a.np_comp = (const cplx*)ctx->d_np_comp;
+  a.r_fs = 1.0 / (double)fs;          // numpy divides a complex array by a real: it multiplies by the rounded reciprocal
+  a.r_s = 1.0 / ctx->np_sumsq;
   a.frames_per_wg = 0;
   static const uint32_t opt_env = [] { const char* e = getenv("SHZ_STFT_OPT"); return e ? (uint32_t)atoi(e) : 0u; }();
   a.opt = opt_env;
@@ -1244,6 +1374,13 @@ static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 
   if (!persistent && chunk_frames && a.total_frames > (uint64_t)grid * chunk_frames) {
     b.frames_per_wg = chunk_frames;
     grid = (a.total_frames + chunk_frames - 1) / chunk_frames;
+  }
+  // fp64 staging follows numpy's arithmetic (stft_np_kernel); SHZ_F64_OWN_FFT=1: this file's own transform, as before round 4
+  static const bool own_f64 = [] { const char* e = getenv("SHZ_F64_OWN_FFT"); return e && atoi(e) != 0; }();
+  if (sizeof(T) == 8 && !own_f64) {
+    hipLaunchKernelGGL(stft_np_kernel, dim3((a.total_frames + NP_FRAMES_PER_WG - 1) / NP_FRAMES_PER_WG), dim3(256), 0, ctx->stream, a);
+    SHZ_HIP(ctx, hipGetLastError());
+    return SHZ_OK;
   }
   hipLaunchKernelGGL(stft_psd_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, b);
   SHZ_HIP(ctx, hipGetLastError());

@@ -98,6 +98,12 @@ struct shz_ctx {
   int16_t* d_sine_lut = nullptr;
   double m_votes_per_hash = 0.0;   // votes per query hash of the last match sub-batch: sizes the next one before it is tried
   double win_sumsq = 0.0;
+  // numpy's own tables (shz_numpy_tables): np.hanning(4096), pocketfft's twiddles exp(-2 pi i k / 4096) as its
+  // sincos_2pibyn computes them, sum(window ** 2) in numpy's pairwise order -- for the fp64 path that follows numpy's
+  // arithmetic operation by operation (stft_np_kernel / peak_verify_kernel)
+  double* d_np_window = nullptr;
+  double2* d_np_comp = nullptr;
+  double np_sumsq = 0.0;
   uint32_t hop = SHZ_HOP;          // new samples per frame: NFFT - noverlap (shz_set_overlap; the reference's wratio)
   // timers / profiling
   hipEvent_t tev[16][2];
@@ -146,6 +152,7 @@ hipError_t shz_memcpy(shz_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
 
 // pinned host memory owned by the ctx for small latency-critical transfers (counts, result blocks, query uploads):
 // grows to the largest request; contents are the caller's between two calls
+void shz_numpy_tables_host(uint32_t n, double* window, double2* comp, double* sumsq);
 int32_t shz_mailbox(shz_ctx* ctx, uint64_t bytes, void** out);
 
 // Big blocks with reuse.  A hipFree'd gigabyte comes back from the driver scrubbed at ~40 GB/s on its next use (measured:

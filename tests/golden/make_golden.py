@@ -185,8 +185,51 @@ def param_variants(ref):
     np.savez_compressed(os.path.join(HERE, "param_variants.npz"), **var)
 
 
+def psd_inputs():
+    """name -> (pcm, Fs, wratio) of the spectrogram digests: the tie inputs, a white and a tonal 30 s clip, a clip shorter than a
+    window, the variant clip at other overlaps and rates, three edge cases.  Regenerable from integers alone (oracle/synth,
+    seeded numpy integers), so the GPU box needs no audio."""
+    cases = {name: (x, 44100, 0.5) for name, x in synth.tie_inputs().items()}
+    cases["white_30s"] = (synth.synth_clip(1234, 1, 1323000, 0, 8000), 44100, 0.5)
+    cases["tonal_30s"] = (synth.synth_clip(1234, 2, 1323000, 4000, 1500), 44100, 0.5)
+    xv = synth.synth_clip(1234, 7, 2048 * 90 + 5, 4000, 1500)
+    cases["variant_wr075"] = (xv, 44100, 0.75)
+    cases["variant_wr08999"] = (xv, 44100, 0.8999)
+    cases["variant_wr0"] = (xv, 44100, 0.0)
+    cases["variant_fs8000"] = (xv, 8000, 0.5)
+    cases["variant_fs48000"] = (xv, 48000, 0.5)
+    cases["short_1500"] = (xv[:1500].copy(), 44100, 0.5)
+    for k in ("exact_4096", "silence_20000", "loud_fullscale"):
+        cases["edge_" + k] = (edge_inputs()[k], 44100, 0.5)
+    return cases
+
+
+def psd_digests(ref):
+    """(vi) the reference's own spectrogram, every bit of it: sha256 over mlab.specgram(...)[0] of the call in
+    __init__.py:232-237 (float64 [2049][F], C order, exact zeros written as 1.0 -- what the device stages), plus a few
+    values in hex.  The device's fp64 path follows numpy's arithmetic operation by operation and must hit these digests."""
+    from matplotlib import mlab
+    out = {"_note": "sha256 of np.where(P == 0, 1.0, P).tobytes(), P = mlab.specgram(x, NFFT=4096, Fs, window_hanning, "
+                    "noverlap=int(4096 * wratio))[0] as computed on the host that made the other fixtures",
+           "_numpy": np.__version__}
+    for name, (x, fs, wr) in psd_inputs().items():
+        P = mlab.specgram(x, NFFT=ref.DEFAULT_WINDOW_SIZE, Fs=fs, window=mlab.window_hanning,
+                          noverlap=int(ref.DEFAULT_WINDOW_SIZE * wr))[0]
+        P = np.ascontiguousarray(np.where(P == 0, 1.0, P), np.float64)
+        rng = np.random.default_rng(7)
+        pf, pt = rng.integers(0, P.shape[0], 6), rng.integers(0, P.shape[1], 6)
+        out[name] = {"Fs": fs, "wratio": wr, "samples": int(len(x)), "pcm_sha256": sha256(x.tobytes()), "shape": list(P.shape),
+                     "sha256": sha256(P.tobytes()), "zeros": int((P == 1.0).sum()),
+                     "probe": [[int(a), int(b), float(P[a, b]).hex()] for a, b in zip(pf, pt)]}
+        print("psd", name, P.shape, out[name]["sha256"][:16])
+    with open(os.path.join(HERE, "psd_digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ref = load_reference_extraction()
+    if "--only-psd" in sys.argv:
+        return psd_digests(ref)
     if "--only-ties" in sys.argv:
         return tie_cases(ref)
     if "--only-variants" in sys.argv:
@@ -245,6 +288,7 @@ def main():
     param_variants(ref)
 
     tie_cases(ref)
+    psd_digests(ref)
 
     # (iv) match / align goldens ---------------------------------------------------------------
     db = StandInDB()
