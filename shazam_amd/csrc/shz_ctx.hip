@@ -281,6 +281,18 @@ extern "C" int32_t shz_ctx_create(int32_t device_id, shz_ctx** out) {
   std::vector<double> npw(SHZ_NFFT);
   std::vector<double2> npc(SHZ_NFFT);
   shz_numpy_tables_host(SHZ_NFFT, npw.data(), npc.data(), &ctx->np_sumsq);
+  {  // the twiddles in the order the passes read them (pocketfft's own per-pass tables: [c - 1][i] = comp[c l1 i]): copies,
+     // no arithmetic -- neighbouring lanes then read neighbouring entries instead of 64 cache lines a load
+    std::vector<double2> tw(SHZ_NFFT, double2{0.0, 0.0});
+    size_t base = 0;
+    for (uint32_t l1 = 1; l1 < SHZ_NFFT; l1 *= 8) {
+      const uint32_t ido = SHZ_NFFT / (8 * l1);
+      for (uint32_t c = 1; c < 8; ++c)
+        for (uint32_t i = 0; i < ido; ++i) tw[base + (size_t)(c - 1) * ido + i] = npc[(size_t)c * l1 * i];
+      base += (size_t)7 * ido;
+    }
+    npc.swap(tw);
+  }
   bool ok = hipMalloc(&ctx->d_np_window, sizeof(double) * SHZ_NFFT) == hipSuccess &&
             hipMalloc(&ctx->d_np_comp, sizeof(double2) * SHZ_NFFT) == hipSuccess &&
             hipMemcpy(ctx->d_np_window, npw.data(), sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice) == hipSuccess &&

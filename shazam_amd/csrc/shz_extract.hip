@@ -394,11 +394,13 @@ __device__ __forceinline__ void np_bfly8(const cplx (&c)[8], cplx (&o)[8]) {
 }
 // buf: the 4096 complex inputs in natural order; 256 threads; the caller has put a barrier behind its stores.  Returns with
 // the transform in buf, natural order, behind a barrier.
-__device__ __forceinline__ void np_fft4096(cplx* buf, const cplx* __restrict__ comp, int j) {
+// tw: the twiddles pass by pass, [c - 1][i] = comp[c l1 i] (pocketfft's per-pass tables; shz_ctx_create copies them there)
+__device__ __forceinline__ void np_fft4096(cplx* buf, const cplx* __restrict__ tw, int j) {
 #pragma unroll 1
   for (int p = 0; p < 4; ++p) {
     const int ls = 3 * p, is = 9 - 3 * p;             // l1 = 8^p butterflies groups, ido = 512 / 8^p
     const int ido = 1 << is;
+    const cplx* __restrict__ twp = tw + 7 * (p == 0 ? 0 : p == 1 ? 512 : p == 2 ? 576 : 584);   // behind the tables of the passes in front (7 ido entries each)
     cplx o[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -409,7 +411,7 @@ __device__ __forceinline__ void np_fft4096(cplx* buf, const cplx* __restrict__ c
       np_bfly8(c, o[u]);
       if (i != 0) {
 #pragma unroll
-        for (int cc = 1; cc < 8; ++cc) o[u][cc] = np_smul(o[u][cc], comp[(cc * i) << ls]);
+        for (int cc = 1; cc < 8; ++cc) o[u][cc] = np_smul(o[u][cc], twp[((cc - 1) << is) + i]);
       }
     }
     __syncthreads();   // every butterfly holds its inputs
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void stft_np_kernel(stft_args a) {
   double2 ww[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.np_window + 2 * (j + 256 * t));
-  const uint32_t g0 = blockIdx.x * NP_FRAMES_PER_WG, gend = min(g0 + NP_FRAMES_PER_WG, a.total_frames);
+  const uint32_t g0 = blockIdx.x * a.frames_per_wg, gend = min(g0 + a.frames_per_wg, a.total_frames);
   uint32_t lo = 0;
   for (uint32_t g = g0; g < gend; ++g) {
     if (g == g0) {
@@ -1378,7 +1380,9 @@ static int32_t launch_stft(shz_ctx* ctx, const stft_args& a, int wgs_override = 
   // fp64 staging follows numpy's arithmetic (stft_np_kernel); SHZ_F64_OWN_FFT=1: this file's own transform, as before round 4
   static const bool own_f64 = [] { const char* e = getenv("SHZ_F64_OWN_FFT"); return e && atoi(e) != 0; }();
   if (sizeof(T) == 8 && !own_f64) {
-    hipLaunchKernelGGL(stft_np_kernel, dim3((a.total_frames + NP_FRAMES_PER_WG - 1) / NP_FRAMES_PER_WG), dim3(256), 0, ctx->stream, a);
+    stft_args c = a;   // a clip or two (the per-clip fallback): one frame a workgroup, so that the whole chip takes part
+    c.frames_per_wg = a.total_frames >= 4u * NP_FRAMES_PER_WG * (uint32_t)ctx->prop.multiProcessorCount ? NP_FRAMES_PER_WG : 1u;
+    hipLaunchKernelGGL(stft_np_kernel, dim3((a.total_frames + c.frames_per_wg - 1) / c.frames_per_wg), dim3(256), 0, ctx->stream, c);
     SHZ_HIP(ctx, hipGetLastError());
     return SHZ_OK;
   }
