@@ -1651,7 +1651,9 @@ __device__ __forceinline__ uint64_t vt_wave_max64(uint64_t v) {
   return ((uint64_t)h << 32) | l;
 }
 // counter of a (song | delta) key, 12 bits: the multiply is 24-bit (full rate); the bits above 24 are folded in first
-#define VW_SEED_TILES 16u      // tiles at the head of a query that fold undecided batches on the spot (vt_stream2_kernel)
+#ifndef VW_SEED_TILES
+#define VW_SEED_TILES 64u      // tiles at the head of a query that fold undecided batches on the spot (vt_stream2_kernel)
+#endif
 #define VW_FILTER_MAX 200u     // a counter that gets here sends its batch to the exact fold whatever the bar (8 bits wrap at 256)
 __device__ __forceinline__ uint32_t vw_hash_filter(uint32_t x) { return (__umul24((x ^ (x >> 13)) & 0xFFFFFFu, 0x9E3779u) >> 11) & 4095u; }
 static_assert(VW_S1 * 8 == 4096, "table 1 (keys + counts) is 4 KB: 4,096 eight-bit counters");
