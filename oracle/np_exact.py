@@ -115,19 +115,79 @@ def _pass8(cr, ci, l1, ido, wr, wi):
     return outr.reshape(-1), outi.reshape(-1)
 
 
-def fft_pow8(x):
-    """np.fft.fft of one real or complex vector whose length is a power of 8, as numpy 2.x computes it."""
+def _pass4(cr, ci, l1, ido, wr, wi):
+    """pocketfft pass4<fwd=true>: cc[i + ido (b + 4 k)] -> ch[i + ido (k + l1 c)]."""
+    cr, ci = cr.reshape(l1, 4, ido), ci.reshape(l1, 4, ido)
+    c = [(cr[:, b, :], ci[:, b, :]) for b in range(4)]
+    add = lambda p, q: (p[0] + q[0], p[1] + q[1])
+    sub = lambda p, q: (p[0] - q[0], p[1] - q[1])
+    t2, t1 = add(c[0], c[2]), sub(c[0], c[2])
+    t3, t4 = add(c[1], c[3]), sub(c[1], c[3])
+    t4 = (t4[1], -t4[0])                                  # ROTX90<fwd>
+    o = [add(t2, t3), add(t1, t4), sub(t2, t3), sub(t1, t4)]
+    return _twiddle_out(o, l1, ido, wr, wi)
+
+
+def _pass2(cr, ci, l1, ido, wr, wi):
+    """pocketfft pass2<fwd=true>."""
+    cr, ci = cr.reshape(l1, 2, ido), ci.reshape(l1, 2, ido)
+    a, b = (cr[:, 0, :], ci[:, 0, :]), (cr[:, 1, :], ci[:, 1, :])
+    o = [(a[0] + b[0], a[1] + b[1]), (a[0] - b[0], a[1] - b[1])]
+    return _twiddle_out(o, l1, ido, wr, wi)
+
+
+def _twiddle_out(o, l1, ido, wr, wi):
+    """outputs c >= 1 times conj(comp[c l1 i]) for i > 0 (special_mul<fwd>), no product at i = 0; layout [c][k][i]"""
+    ip = len(o)
+    outr, outi = np.empty((ip, l1, ido)), np.empty((ip, l1, ido))
+    i = np.arange(ido)
+    for cc in range(ip):
+        vr, vi = o[cc]
+        if cc and ido > 1:
+            w_r, w_i = wr[cc * l1 * i], wi[cc * l1 * i]
+            tr, ti = vr * w_r + vi * w_i, vi * w_r - vr * w_i
+            tr[:, 0], ti[:, 0] = vr[:, 0], vi[:, 0]
+            vr, vi = tr, ti
+        outr[cc], outi[cc] = vr, vi
+    return outr.reshape(-1), outi.reshape(-1)
+
+
+def factors_pow2(n: int):
+    """pocketfft cfftp::factorize for a power of two: 8s, then 4s, then one 2 -- which goes to the FRONT of the list."""
+    f, ln = [], n
+    while ln & 7 == 0:
+        f.append(8)
+        ln >>= 3
+    while ln & 3 == 0:
+        f.append(4)
+        ln >>= 2
+    if ln & 1 == 0:
+        ln >>= 1
+        f.append(2)
+        f[0], f[-1] = f[-1], f[0]
+    assert ln == 1, "powers of two only"
+    return f
+
+
+def fft_pow2(x):
+    """np.fft.fft of one real or complex vector whose length is a power of two, as numpy 2.x computes it."""
     x = np.asarray(x)
     n = len(x)
-    assert n >= 8 and 8 ** round(np.log(n) / np.log(8)) == n
     cr, ci = np.array(x.real, np.float64), np.array(x.imag, np.float64)
+    if n == 1:
+        return cr + 1j * ci
     wr, wi = sincos_2pibyn(n)
     l1 = 1
-    while l1 < n:
-        ido = n // (8 * l1)
-        cr, ci = _pass8(cr, ci, l1, ido, wr, wi)
-        l1 *= 8
+    for ip in factors_pow2(n):
+        ido = n // (ip * l1)
+        cr, ci = {8: _pass8, 4: _pass4, 2: _pass2}[ip](cr, ci, l1, ido, wr, wi)
+        l1 *= ip
     return cr + 1j * ci
+
+
+def fft_pow8(x):
+    """(the 4096-point case and its smaller relatives: radix-8 passes only)"""
+    return fft_pow2(x)
 
 
 def psd_exact(x, Fs=44100, noverlap=2048, nfft=4096) -> np.ndarray:
@@ -142,7 +202,7 @@ def psd_exact(x, Fs=44100, noverlap=2048, nfft=4096) -> np.ndarray:
     frames = np.lib.stride_tricks.sliding_window_view(x, nfft)[:: nfft - noverlap]
     out = np.empty((nfft // 2 + 1, frames.shape[0]))
     for f, fr in enumerate(frames):
-        z = fft_pow8(fr * w)[: nfft // 2 + 1]
+        z = fft_pow2(fr * w)[: nfft // 2 + 1]
         re, im = z.real.copy(), z.imag.copy()
         p = _fma(re, re, im * im).astype(np.float64)
         p[1:-1] *= 2.0

@@ -1547,16 +1547,24 @@ extern "C" int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Window sizes other than 4096 (fingerprint(..., wsize=...), __init__.py:212-217, 232-237): a GENERIC spectrogram, correct
-// and not fast -- nobody's hot path: the reference and all its callers use 4096.  One workgroup per frame, radix-2 Stockham
-// through two LDS buffers in fp64, window and twiddles from tables the host computes in long double; mlab's scaling
-// (mlab:339-354) and the reference's log rule (__init__.py:241).  Output in the reference's [bins][frames] layout, so that
-// get_2D_peaks / generate_hashes (shz_peaks_from_db, shz_pair_hash) take it from there as the reference's own fingerprint()
-// composes them.  nfft: a power of two in [64, 2048] (two buffers of nfft complex doubles are 64 KB of LDS at 2048; 8192 has
-// no packed key: key32 gives a frequency 12 bits).
+// Window sizes other than 4096 (fingerprint(..., wsize=...), __init__.py:212-217, 232-237): a GENERIC spectrogram, not fast
+// -- nobody's hot path: the reference and all its callers use 4096 -- but with the reference's arithmetic like the fp64 path
+// of the 4096 case (np_fft4096 above): numpy's window, pocketfft's plan for the size (for a power of two: radix-8 passes,
+// then radix 4, and a single radix-2 pass that goes FIRST: 2048 = 8.8.8.4, 1024 = 2.8.8.8, 256 = 8.8.4, 128 = 2.8.8), its
+// pass2 / pass4 / pass8 butterflies operation by operation, numpy's complex product and mlab's scaling.  One workgroup per
+// frame, two LDS buffers.  Output in the reference's [bins][frames] layout, so that get_2D_peaks / generate_hashes
+// (shz_peaks_from_db, shz_pair_hash) take it from there as the reference's own fingerprint() composes them.  nfft: a power
+// of two in [64, 2048] (two buffers of nfft complex doubles are 64 KB of LDS at 2048; 8192 has no packed key: key32 gives a
+// frequency 12 bits).
+#define ANY_MAX_PASSES 6
+struct any_plan {
+  uint32_t npass;
+  uint32_t ip[ANY_MAX_PASSES], l1[ANY_MAX_PASSES], ido[ANY_MAX_PASSES], twoff[ANY_MAX_PASSES];   // twoff: into tw, [c - 1][i] = comp[c l1 i]
+};
+
 __global__ __launch_bounds__(256) void stft_any_kernel(const int16_t* __restrict__ pcm, uint64_t n, uint32_t nfft, uint32_t hop,
                                                        uint32_t F, const double* __restrict__ window, const cplx* __restrict__ tw,
-                                                       double scale, int as_power, double* __restrict__ out) {
+                                                       any_plan pl, double r_fs, double r_s, int as_power, double* __restrict__ out) {
   extern __shared__ cplx gs_lds[];
   cplx* a = gs_lds;
   cplx* b = gs_lds + nfft;
@@ -1568,22 +1576,46 @@ __global__ __launch_bounds__(256) void stft_any_kernel(const int16_t* __restrict
     a[i] = make_double2(x * window[i], 0.0);
   }
   __syncthreads();
-  for (uint32_t Ns = 1; Ns < nfft; Ns <<= 1) {
-    const uint32_t tstep = nfft / (2 * Ns);   // W_{2 Ns}^k = W_nfft^(k tstep)
-    for (uint32_t j = tid; j < half; j += 256) {
-      const uint32_t k = j & (Ns - 1);
-      const cplx u = a[j], v = cmul(a[j + half], tw[k * tstep]);
-      const uint32_t j0 = ((j - k) << 1) + k;
-      b[j0] = cadd(u, v);
-      b[j0 + Ns] = csub(u, v);
+  for (uint32_t p = 0; p < pl.npass; ++p) {   // uniform
+    const uint32_t ip = pl.ip[p], l1 = pl.l1[p], ido = pl.ido[p];
+    const cplx* __restrict__ twp = tw + pl.twoff[p];
+    for (uint32_t bf = tid; bf < l1 * ido; bf += 256) {
+      const uint32_t k = bf / ido, i = bf - k * ido;
+      // inputs cc[i + ido (q + ip k)], outputs ch[i + ido (k + l1 c)], c >= 1 and i > 0 times conj(comp[c l1 i])
+      if (ip == 8) {
+        cplx c[8], o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = a[i + ido * (q + 8 * k)];
+        np_bfly8(c, o);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) b[i + ido * (k + l1 * cc)] = (cc && i) ? np_smul(o[cc], twp[(cc - 1) * ido + i]) : o[cc];
+      } else if (ip == 4) {
+        const cplx c0 = a[i + ido * (4 * k)], c1 = a[i + ido * (1 + 4 * k)], c2 = a[i + ido * (2 + 4 * k)], c3 = a[i + ido * (3 + 4 * k)];
+        const cplx t2 = cadd(c0, c2), t1 = csub(c0, c2);            // PM(t2, t1, c0, c2)
+        const cplx t3 = cadd(c1, c3);
+        cplx t4 = csub(c1, c3);                                     // PM(t3, t4, c1, c3)
+        t4 = make_double2(t4.y, -t4.x);                             // ROTX90<fwd>(t4)
+        const cplx o0 = cadd(t2, t3), o1 = cadd(t1, t4), o2 = csub(t2, t3), o3 = csub(t1, t4);
+        b[i + ido * k] = o0;
+        b[i + ido * (k + l1)] = i ? np_smul(o1, twp[i]) : o1;
+        b[i + ido * (k + 2 * l1)] = i ? np_smul(o2, twp[ido + i]) : o2;
+        b[i + ido * (k + 3 * l1)] = i ? np_smul(o3, twp[2 * ido + i]) : o3;
+      } else {
+        const cplx c0 = a[i + ido * (2 * k)], c1 = a[i + ido * (1 + 2 * k)];
+        const cplx o1 = csub(c0, c1);
+        b[i + ido * k] = cadd(c0, c1);
+        b[i + ido * (k + l1)] = i ? np_smul(o1, twp[i]) : o1;
+      }
     }
     __syncthreads();
     cplx* t = a; a = b; b = t;
   }
   for (uint32_t k = tid; k <= half; k += 256) {
     const cplx X = a[k];
-    const double sc = (k != 0 && k != half) ? 2.0 * scale : scale;
-    const double p = fma(X.x, X.x, X.y * X.y) * sc;
+    double p = fma(X.x, X.x, X.y * X.y);
+    if (k != 0 && k != half) p *= 2.0;
+    p = p * r_fs;
+    p = p * r_s;
     out[(uint64_t)k * F + f] = as_power ? p : (p != 0.0 ? shz_db_of(p) : 0.0);
   }
 }
@@ -1605,32 +1637,43 @@ extern "C" int32_t shz_stft_db_any(shz_ctx* ctx, const int16_t* pcm, uint64_t n_
   if (n_frames) *n_frames = F;
   if ((uint64_t)F * bins > cap_doubles || !out_db) SHZ_FAIL(ctx, SHZ_E_CAPACITY, "shz_stft_db_any: need %llu doubles", (unsigned long long)F * bins);
   SHZ_HIP(ctx, hipSetDevice(ctx->device));
-  // tables: np.hanning(nfft) (symmetric, mlab:58-66) and W_nfft^k, in long double like the 4096 tables of the context
+  // numpy's tables for this size (shz_numpy_tables), the twiddles laid out pass by pass; pocketfft's factor list of a power
+  // of two: 8s, then 4s, then one 2 -- which is moved to the FRONT
   std::vector<double> win(nfft);
-  std::vector<cplx> tw(nfft / 2);
-  const long double pi = 3.14159265358979323846264338327950288L;
+  std::vector<double2> comp(nfft), tw(nfft);
   double sumsq = 0.0;
-  for (uint32_t i = 0; i < nfft; ++i) {
-    const long double nn = (long double)(1 - (long)nfft + 2 * (long)i);
-    win[i] = (double)(0.5L + 0.5L * cosl(pi * nn / (long double)(nfft - 1)));
-  }
-  for (uint32_t i = 0; i < nfft; ++i) sumsq += win[i] * win[i];
-  for (uint32_t k = 0; k < nfft / 2; ++k) {
-    const long double ang = -2.0L * pi * (long double)k / (long double)nfft;
-    tw[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+  shz_numpy_tables_host(nfft, win.data(), comp.data(), &sumsq);
+  any_plan pl;
+  memset(&pl, 0, sizeof(pl));
+  {
+    uint32_t fct[ANY_MAX_PASSES], nf = 0, len = nfft;
+    while ((len & 7) == 0) { fct[nf++] = 8; len >>= 3; }
+    while ((len & 3) == 0) { fct[nf++] = 4; len >>= 2; }
+    if ((len & 1) == 0) { len >>= 1; fct[nf++] = 2; std::swap(fct[0], fct[nf - 1]); }
+    uint32_t l1 = 1, off = 0;
+    for (uint32_t p = 0; p < nf; ++p) {
+      const uint32_t ip = fct[p], ido = nfft / (l1 * ip);
+      pl.ip[p] = ip; pl.l1[p] = l1; pl.ido[p] = ido; pl.twoff[p] = off;
+      for (uint32_t c = 1; c < ip; ++c)
+        for (uint32_t i = 0; i < ido; ++i) tw[off + (c - 1) * ido + i] = comp[(size_t)c * l1 * i];
+      off += (ip - 1) * ido;
+      l1 *= ip;
+    }
+    pl.npass = nf;
   }
   void *d_pcm, *d_win, *d_tw, *d_out;
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_PCM, n_samples * 2 + 64, &d_pcm));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC0, (uint64_t)nfft * 8 + 64, &d_win));
-  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)nfft * 8 + 64, &d_tw));
+  SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_MISC1, (uint64_t)nfft * 16 + 64, &d_tw));
   SHZ_TRY(shz_ws_reserve(ctx, SHZ_WS_DB, (uint64_t)F * bins * 8 + 64, &d_out));
   SHZ_HIP(ctx, shz_memcpy(ctx, d_pcm, pcm, n_samples * 2, hipMemcpyHostToDevice));
   SHZ_HIP(ctx, shz_memcpy(ctx, d_win, win.data(), (uint64_t)nfft * 8, hipMemcpyHostToDevice));
-  SHZ_HIP(ctx, shz_memcpy(ctx, d_tw, tw.data(), (uint64_t)nfft * 8, hipMemcpyHostToDevice));
+  SHZ_HIP(ctx, shz_memcpy(ctx, d_tw, tw.data(), (uint64_t)nfft * 16, hipMemcpyHostToDevice));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the host tables go out of scope)
-  const double scale = 1.0 / ((double)fs * sumsq);   // P / Fs / sum(w^2), mlab:350-354
+  // P * 2 (bins 1 .. N/2 - 1), / Fs, / sum(w^2) as numpy does them: the divisions are products with the rounded reciprocals
   hipLaunchKernelGGL(stft_any_kernel, dim3(F), dim3(256), (size_t)nfft * 2 * sizeof(cplx), ctx->stream, (const int16_t*)d_pcm, n_samples,
-                     nfft, hop, F, (const double*)d_win, (const cplx*)d_tw, scale, (flags & SHZ_STFT_POWER) ? 1 : 0, (double*)d_out);
+                     nfft, hop, F, (const double*)d_win, (const cplx*)d_tw, pl, 1.0 / (double)fs, 1.0 / sumsq,
+                     (flags & SHZ_STFT_POWER) ? 1 : 0, (double*)d_out);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_HIP(ctx, shz_memcpy(ctx, out_db, d_out, (uint64_t)F * bins * 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -201,6 +201,10 @@ def psd_inputs():
     cases["short_1500"] = (xv[:1500].copy(), 44100, 0.5)
     for k in ("exact_4096", "silence_20000", "loud_fullscale"):
         cases["edge_" + k] = (edge_inputs()[k], 44100, 0.5)
+    # other window sizes (a 4th element: NFFT): numpy's plans 8.8.8.4, 2.8.8.8, 8.8.8, 8.8.4, 2.8.8, 8.8
+    for nfft, wr in ((2048, 0.5), (1024, 0.5), (512, 0.75), (256, 0.0), (128, 0.5), (64, 0.5)):
+        cases[f"ws{nfft}"] = (xv[: 40 * nfft + 13].copy(), 44100, wr, nfft)
+    cases["ws2048_short"] = (xv[:1500].copy(), 44100, 0.5, 2048)
     return cases
 
 
@@ -212,13 +216,14 @@ def psd_digests(ref):
     out = {"_note": "sha256 of np.where(P == 0, 1.0, P).tobytes(), P = mlab.specgram(x, NFFT=4096, Fs, window_hanning, "
                     "noverlap=int(4096 * wratio))[0] as computed on the host that made the other fixtures",
            "_numpy": np.__version__}
-    for name, (x, fs, wr) in psd_inputs().items():
-        P = mlab.specgram(x, NFFT=ref.DEFAULT_WINDOW_SIZE, Fs=fs, window=mlab.window_hanning,
-                          noverlap=int(ref.DEFAULT_WINDOW_SIZE * wr))[0]
+    for name, case in psd_inputs().items():
+        x, fs, wr = case[:3]
+        nfft = case[3] if len(case) > 3 else ref.DEFAULT_WINDOW_SIZE
+        P = mlab.specgram(x, NFFT=nfft, Fs=fs, window=mlab.window_hanning, noverlap=int(nfft * wr))[0]
         P = np.ascontiguousarray(np.where(P == 0, 1.0, P), np.float64)
         rng = np.random.default_rng(7)
         pf, pt = rng.integers(0, P.shape[0], 6), rng.integers(0, P.shape[1], 6)
-        out[name] = {"Fs": fs, "wratio": wr, "samples": int(len(x)), "pcm_sha256": sha256(x.tobytes()), "shape": list(P.shape),
+        out[name] = {"Fs": fs, "wratio": wr, "nfft": int(nfft), "samples": int(len(x)), "pcm_sha256": sha256(x.tobytes()), "shape": list(P.shape),
                      "sha256": sha256(P.tobytes()), "zeros": int((P == 1.0).sum()),
                      "probe": [[int(a), int(b), float(P[a, b]).hex()] for a, b in zip(pf, pt)]}
         print("psd", name, P.shape, out[name]["sha256"][:16])

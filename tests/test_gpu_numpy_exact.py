@@ -12,7 +12,10 @@ from test_numpy_tables import psd_cases
 pytestmark = pytest.mark.gpu
 
 
-def _power(ctx, x, wratio, fs):
+def _power(ctx, x, wratio, fs, nfft=4096):
+    if nfft != 4096:   # the generic spectrogram (other window sizes)
+        P = ctx.stft_db_any(np.ascontiguousarray(x, np.int16), fs, nfft, int(nfft * wratio), power=True)
+        return np.where(P == 0, 1.0, P)
     ctx.set_overlap(int(4096 * wratio))
     try:
         return ctx.stft_db(np.ascontiguousarray(x, np.int16), np.array([0, len(x)], np.uint64), fs=fs, power=True)[0]
@@ -24,7 +27,7 @@ def test_power_spectrogram_is_the_references_bit_for_bit(golden_dir):
     import shazam_amd as S
     ctx = S.get_context(0)
     for name, (x, d) in psd_cases(golden_dir).items():
-        P = _power(ctx, x, d["wratio"], d["Fs"])
+        P = _power(ctx, x, d["wratio"], d["Fs"], d["nfft"])
         assert list(P.shape) == d["shape"], name
         assert int((P == 1.0).sum()) >= d["zeros"], name
         for a, b, v in d["probe"]:

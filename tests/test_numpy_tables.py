@@ -17,7 +17,7 @@ def _tables(n):
     return w, tw[0::2].copy(), tw[1::2].copy(), s.value
 
 
-@pytest.mark.parametrize("n", [4096, 512, 64])
+@pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256, 128, 64])
 def test_library_tables_are_numpys(n):
     from oracle import np_exact as E
     w, tr, ti, s = _tables(n)
@@ -29,13 +29,13 @@ def test_library_tables_are_numpys(n):
     assert np.abs(tr - np.cos(2 * np.pi * k / n)).max() < 1e-15 and np.abs(ti - np.sin(2 * np.pi * k / n)).max() < 1e-15   # (the comparison value carries the error of its argument)
 
 
-@pytest.mark.parametrize("n", [8, 64, 512, 4096])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_restated_passes_are_numpys_fft_bit_for_bit(n):
     from oracle import np_exact as E
     rng = np.random.default_rng(n)
     for x in (rng.standard_normal(n), rng.integers(-32768, 32767, n) * np.hanning(n), rng.standard_normal(n) + 1j * rng.standard_normal(n),
               np.zeros(n), np.eye(1, n, 3)[0]):
-        got, want = E.fft_pow8(x), np.fft.fft(x)
+        got, want = E.fft_pow2(x), np.fft.fft(x)
         assert np.array_equal(got.real, want.real) and np.array_equal(got.imag, want.imag)
 
 
@@ -52,18 +52,21 @@ def psd_cases(golden_dir):
     spec.loader.exec_module(mod)
     dig = json.load(open(os.path.join(golden_dir, "psd_digests.json")))
     out = {}
-    for name, (x, fs, wr) in mod.psd_inputs().items():
+    for name, case in mod.psd_inputs().items():
+        x, fs, wr = case[:3]
         d = dig[name]
         assert hashlib.sha256(x.tobytes()).hexdigest() == d["pcm_sha256"] and d["Fs"] == fs and d["wratio"] == wr
+        assert d["nfft"] == (case[3] if len(case) > 3 else 4096)
         out[name] = (x, d)
     return out
 
 
-@pytest.mark.parametrize("name", ["short_1500", "edge_exact_4096", "edge_silence_20000", "variant_wr0", "edge_loud_fullscale"])
+@pytest.mark.parametrize("name", ["short_1500", "edge_exact_4096", "edge_silence_20000", "variant_wr0", "edge_loud_fullscale",
+                                  "ws2048", "ws1024", "ws512", "ws256", "ws128", "ws64", "ws2048_short"])
 def test_oracle_spectrogram_hits_the_references_digest(golden_dir, name):
     from oracle import np_exact as E
     x, d = psd_cases(golden_dir)[name]
-    P = E.psd_exact(x, d["Fs"], int(4096 * d["wratio"]))
+    P = E.psd_exact(x, d["Fs"], int(d["nfft"] * d["wratio"]), d["nfft"])
     assert list(P.shape) == d["shape"]
     for a, b, v in d["probe"]:
         assert float(np.where(P == 0, 1.0, P)[a, b]).hex() == v
