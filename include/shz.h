@@ -147,7 +147,11 @@ uint32_t shz_frame_count(uint64_t n_samples);
  * blocks concatenated in clip order; cap_doubles = capacity of out_db in doubles.
  * The logarithm is the correctly rounded one (csrc/shz_log10.h).  With SHZ_STFT_POWER the block holds what
  * specgram returns (the PSD before the log, __init__.py:232-237) in the staged form peak picking reads:
- * exact zeros read as 1.0, the power whose dB value is the 0.0 the reference assigns them (:241). */
+ * exact zeros read as 1.0, the power whose dB value is the 0.0 the reference assigns them (:241).
+ * The power is computed with the reference's arithmetic operation by operation (numpy 2.x: pocketfft's radix-8 passes on the
+ * complex frame, its complex product on a host with FMA3, mlab's scaling: csrc/shz_extract.hip np_fft4096): every value is
+ * the one specgram returns, bit for bit (tests/golden/psd_digests.json).  The same arithmetic decides every tie of the
+ * batch path (shz_peaks / shz_fingerprint_batch). */
 int32_t shz_stft_db(shz_ctx* ctx, const int16_t* pcm, const uint64_t* clip_off, uint32_t n_clips,
                     uint32_t fs, uint32_t flags, double* out_db, uint64_t cap_doubles, uint64_t* count);
 
