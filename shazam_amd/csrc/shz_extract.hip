@@ -80,6 +80,7 @@ struct stft_args {
   const double* window;        // [4096]
   const cplx* tw;              // [1025] W4096^k
   double scale;                // 0.25 / (Fs * sum(w^2))
+  double wscale;               // sqrt(2 scale): the kernel scales its window registers once, |X|^2 then IS the doubled, scaled power
   uint32_t opt;                // experiment switches (SHZ_STFT_OPT): 1 = no rotation of the special wave, 2 = one frame loop for all waves
   uint32_t hop;                // new samples per frame = NFFT - noverlap (mlab:307-308); 2,048 unless shz_set_overlap says otherwise
   // numpy's arithmetic (stft_np_kernel, peak_verify_kernel): np.hanning(4096), pocketfft's twiddles, 1 / Fs, 1 / sum(w^2)
@@ -135,6 +136,96 @@ __device__ __forceinline__ void dft8f(cplx* v) {
   const cplx c1 = make_double2(fma(s, q3.x, d2.x), fma(s, q3.y, d2.y));
   const cplx c3 = make_double2(fma(-s, q3.x, d2.x), fma(-s, q3.y, d2.y));
   v[0] = b0; v[1] = c0; v[2] = b1; v[3] = c1; v[4] = b2; v[5] = c2; v[6] = b3; v[7] = c3;
+}
+
+// pass 1 takes its inputs straight from the PCM and the window: v[t] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = j + 256 t, and the
+// first stage v[t] +- v[t+4] is one product and two fused steps a component instead of two products, a sum and a difference
+// (STFT_FUSED, below)
+__device__ __forceinline__ void dft8f_tail(cplx b0, cplx b1, cplx b2, cplx b3, cplx b4, cplx b5, cplx b6, cplx b7, cplx* v) {
+  const double s = 0.70710678118654752440;
+  dft4(b0, b1, b2, b3);
+  const cplx p5 = make_double2(b5.x + b5.y, b5.y - b5.x);
+  const cplx p7 = make_double2(b7.y - b7.x, -(b7.x + b7.y));
+  b6 = cmul_negi(b6);
+  const cplx d0 = cadd(b4, b6), d2 = csub(b4, b6);
+  const cplx q1 = cadd(p5, p7), q3 = cmul_negi(csub(p5, p7));
+  const cplx c0 = make_double2(fma(s, q1.x, d0.x), fma(s, q1.y, d0.y));
+  const cplx c2 = make_double2(fma(-s, q1.x, d0.x), fma(-s, q1.y, d0.y));
+  const cplx c1 = make_double2(fma(s, q3.x, d2.x), fma(s, q3.y, d2.y));
+  const cplx c3 = make_double2(fma(-s, q3.x, d2.x), fma(-s, q3.y, d2.y));
+  v[0] = b0; v[1] = c0; v[2] = b1; v[3] = c1; v[4] = b2; v[5] = c2; v[6] = b3; v[7] = c3;
+}
+
+// Twiddle products FUSED into the first additions behind them (round 4).  A butterfly whose inputs carry twiddles first
+// forms a + w b and a - w b; written as product-then-sum that is 4 + 2 + 2 operations, written as
+//   r = fma(-w.y, b.y, fma(w.x, b.x, a.x)) | fma(w.y, b.x, fma(w.x, b.y, a.y))  and  s = 2 a - r   (one fma a component)
+// it is 6: two fewer per twiddled pair -- 32 of the 373 fp64 operations of a frame (passes 2 and 3: the four pairs of each
+// radix-8 butterfly, pass 4: two per radix-4 butterfly, the post-pass: one per bin pair).  The values differ from the
+// unfused form in the last bits, as any two correct transforms do; what decides ties is the reference's own arithmetic
+// (np_fft4096), not this kernel's.  STFT_FUSED=0 builds the unfused form (A/B).
+#ifndef STFT_FUSED
+#define STFT_FUSED 1
+#endif
+__device__ __forceinline__ void cmul_pm(cplx a, cplx w, cplx b, cplx& r, cplx& s) {   // r = a + w b, s = a - w b
+#if STFT_FUSED
+  r = make_double2(fma(-w.y, b.y, fma(w.x, b.x, a.x)), fma(w.y, b.x, fma(w.x, b.y, a.y)));
+  s = make_double2(fma(2.0, a.x, -r.x), fma(2.0, a.y, -r.y));
+#else
+  const cplx t = cmul(b, w);
+  r = cadd(a, t);
+  s = csub(a, t);
+#endif
+}
+// dft8f of v[0], w[0] v[1], ..., w[6] v[7]
+__device__ __forceinline__ void dft8f_tw(cplx* v, const cplx (&w)[7]) {
+  const double s = 0.70710678118654752440;
+  cplx b0, b1, b2, b3, b4, b5, b6, b7;
+  cmul_pm(v[0], w[3], v[4], b0, b4);
+  cmul_pm(cmul(v[1], w[0]), w[4], v[5], b1, b5);
+  cmul_pm(cmul(v[2], w[1]), w[5], v[6], b2, b6);
+  cmul_pm(cmul(v[3], w[2]), w[6], v[7], b3, b7);
+  dft4(b0, b1, b2, b3);
+  const cplx p5 = make_double2(b5.x + b5.y, b5.y - b5.x);
+  const cplx p7 = make_double2(b7.y - b7.x, -(b7.x + b7.y));
+  b6 = cmul_negi(b6);
+  const cplx d0 = cadd(b4, b6), d2 = csub(b4, b6);
+  const cplx q1 = cadd(p5, p7), q3 = cmul_negi(csub(p5, p7));
+  const cplx c0 = make_double2(fma(s, q1.x, d0.x), fma(s, q1.y, d0.y));
+  const cplx c2 = make_double2(fma(-s, q1.x, d0.x), fma(-s, q1.y, d0.y));
+  const cplx c1 = make_double2(fma(s, q3.x, d2.x), fma(s, q3.y, d2.y));
+  const cplx c3 = make_double2(fma(-s, q3.x, d2.x), fma(-s, q3.y, d2.y));
+  v[0] = b0; v[1] = c0; v[2] = b1; v[3] = c1; v[4] = b2; v[5] = c2; v[6] = b3; v[7] = c3;
+}
+// dft4 of c0, w1 c1, w2 c2, w3 c3
+__device__ __forceinline__ void dft4_tw(cplx& c0, cplx& c1, cplx& c2, cplx& c3, cplx w1, cplx w2, cplx w3) {
+  cplx d0, d2, d1, d3;
+  cmul_pm(c0, w2, c2, d0, d2);
+  cmul_pm(cmul(c1, w1), w3, c3, d1, d3);
+  d3 = cmul_negi(d3);
+  c0 = cadd(d0, d1);
+  c1 = cadd(d2, d3);
+  c2 = csub(d0, d1);
+  c3 = csub(d2, d3);
+}
+
+// dft8f of the windowed samples of one thread: pw[t] = packed (x[2n], x[2n+1]), ww[t] = (w[2n], w[2n+1])
+__device__ __forceinline__ void dft8f_win(const int (&pw)[8], const double2 (&ww)[8], cplx* v) {
+  cplx b[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double x0 = (double)(short)(pw[t] & 0xFFFF), y0 = (double)(pw[t] >> 16);
+    const double x4 = (double)(short)(pw[t + 4] & 0xFFFF), y4 = (double)(pw[t + 4] >> 16);
+#if STFT_FUSED
+    const double px = x0 * ww[t].x, py = y0 * ww[t].y;
+    b[t] = make_double2(fma(x4, ww[t + 4].x, px), fma(y4, ww[t + 4].y, py));
+    b[t + 4] = make_double2(fma(-x4, ww[t + 4].x, px), fma(-y4, ww[t + 4].y, py));
+#else
+    const cplx v0 = make_double2(x0 * ww[t].x, y0 * ww[t].y), v4 = make_double2(x4 * ww[t + 4].x, y4 * ww[t + 4].y);
+    b[t] = cadd(v0, v4);
+    b[t + 4] = csub(v0, v4);
+#endif
+  }
+  dft8f_tail(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], v);
 }
 
 // PCM of frame `g` (sub-batch numbering) of clip `lo` as 8 packed sample pairs per thread
@@ -220,8 +311,8 @@ struct stft_tabs { const cplx *tw, *tw2, *tw3; };
 __device__ __forceinline__ stft_tabs stft_tabs_at(const cplx* tw) { return stft_tabs{tw, tw + TW_MAIN, tw + TW_MAIN + TW_P2}; }
 
 // pass 1: Ns = 1 (no twiddles); A1[8j + r] at slot 8j + r
-__device__ __forceinline__ void stft_p1(cplx (&v)[8], cplx* buf, int j) {
-  dft8f(v);
+__device__ __forceinline__ void stft_p1(const int (&pw)[8], const double2 (&ww)[8], cplx (&v)[8], cplx* buf, int j) {
+  dft8f_win(pw, ww, v);
   const int a = stft_szb(8 * j);   // the low three slot bits hold swizzle terms only
 #pragma unroll
   for (int r = 0; r < 8; ++r) lds_at(buf, a ^ (r << 4)) = v[r];
@@ -240,9 +331,10 @@ __device__ __forceinline__ void stft_p2_rest(cplx (&v)[8], cplx* buf, const stft
   const int j2 = (L & 7) | (W << 3) | ((L >> 3) << 5);
   const int a0 = stft_szb(j2), a1 = stft_szb(j2 | 256);
   const int k = L & 7;
+  cplx w[7];
 #pragma unroll
-  for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw2[(t - 1) * 8 + k]);
-  dft8f(v);
+  for (int t = 1; t < 8; ++t) w[t - 1] = T.tw2[(t - 1) * 8 + k];
+  dft8f_tw(v, w);
 #pragma unroll
   for (int r = 0; r < 8; ++r) lds_at(buf, ((r & 1) ? a1 : a0) + (r >> 1) * (512 << 4)) = v[r];
 }
@@ -259,9 +351,10 @@ __device__ __forceinline__ void stft_p3_rest(cplx (&v)[8], cplx* buf, const stft
   const int b3 = stft_szb((j & 7) | ((j >> 6) << 3) | (((j >> 3) & 7) << 8));
   const int q0 = b3, q1 = (b3 ^ (9 << 4)) + (32 << 4), q2 = (b3 ^ (4 << 4)) + (64 << 4), q3 = (b3 ^ (13 << 4)) + (96 << 4);
   const int k = j & 63;
+  cplx w[7];
 #pragma unroll
-  for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], T.tw3[(t - 1) * 64 + k]);
-  dft8f(v);
+  for (int t = 1; t < 8; ++t) w[t - 1] = T.tw3[(t - 1) * 64 + k];
+  dft8f_tw(v, w);
 #pragma unroll
   for (int r = 0; r < 8; ++r) lds_at(buf, ((r & 3) == 0 ? q0 : (r & 3) == 1 ? q1 : (r & 3) == 2 ? q2 : q3) + (r >> 2) * (128 << 4)) = v[r];
 }
@@ -284,7 +377,7 @@ __device__ __forceinline__ void stft_p4_load(cplx (&v)[8], const cplx* buf, int 
 // Thread 0's second butterfly is b = 256, not 512: its twiddles are constants, selected below.
 // SPECIAL = false: the caller knows that no lane of the wave is thread 0 (waves 1-3): the selects fold away.
 template <bool SPECIAL, class PRE, class OUT>
-__device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, int j, double scale, PRE&& before_out, OUT&& out) {
+__device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, int j, PRE&& before_out, OUT&& out) {
   const cplx* tw = T.tw;
   const bool t0 = SPECIAL && j == 0;
   const int bb = t0 ? 256 : 512 - j;
@@ -297,22 +390,21 @@ __device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, i
     const cplx v1 = csel(t0, make_double2(h, -h), tw_mirror(w1));
     const cplx v2 = csel(t0, make_double2(0.0, -1.0), make_double2(-w2.x, w2.y));
     const cplx v3 = csel(t0, make_double2(-h, -h), make_double2(w3.y, w3.x));
-    A1 = cmul(A1, w1); A2 = cmul(A2, w2); A3 = cmul(A3, w3);
-    dft4(A0, A1, A2, A3);
-    B1 = cmul(B1, v1); B2 = cmul(B2, v2); B3 = cmul(B3, v3);
-    dft4(B0, B1, B2, B3);
+    dft4_tw(A0, A1, A2, A3, w1, w2, w3);
+    dft4_tw(B0, B1, B2, B3, v1, v2, v3);
   }
   before_out();
-  const double scale2 = scale * 2.0;  // bins 1..2047 doubled (mlab:339-345)
+  // the window carries sqrt(2 scale) (stft_args::wscale): |X|^2 is the power of bins 1..2047, doubled as mlab doubles them
+  // (mlab:339-345); bins 0 and 2048 -- the pair k = 0, thread 0's -- are not doubled: half of it
   // bins k and 2048 - k from zk = Z[k], zm = Z[2048 - k], k in [0, 1024], wk = W^k
   auto pair_out = [&](int k, cplx wk, cplx zk, cplx zm) {
     const cplx e = make_double2(zk.x + zm.x, zk.y - zm.y);
     const cplx o = make_double2(zk.y + zm.y, zm.x - zk.x);
-    const cplx wo = cmul(wk, o);
-    const cplx xa = cadd(e, wo), xb = csub(e, wo);
-    const double sc = (k != 0) ? scale2 : scale;  // bin 2048 pairs with k = 0: both unscaled
-    const double pa = fma(xa.x, xa.x, xa.y * xa.y) * sc;
-    const double pb = fma(xb.x, xb.x, xb.y * xb.y) * sc;
+    cplx xa, xb;
+    cmul_pm(e, wk, o, xa, xb);
+    double pa = fma(xa.x, xa.x, xa.y * xa.y);
+    double pb = fma(xb.x, xb.x, xb.y * xb.y);
+    if (SPECIAL && k == 0) { pa *= 0.5; pb *= 0.5; }
     out(k, pa);
     if (k != 1024) out(2048 - k, pb);
   };
@@ -331,10 +423,11 @@ __device__ __forceinline__ void stft_p4_rest(cplx (&v)[8], const stft_tabs& T, i
 
 // SPECIAL = false: the caller knows that its wave does not hold thread 0 (see stft_psd_kernel)
 template <bool SPECIAL = true, class PRE, class OUT>
-__device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, double scale, PRE&& before_out, OUT&& out) {
+__device__ __forceinline__ void stft_frame(const int (&pw)[8], const double2 (&ww)[8], cplx* lds, int j, PRE&& before_out, OUT&& out) {
   cplx* buf = lds;
   const stft_tabs T = stft_tabs_at(lds + 2048);
-  stft_p1(v, buf, j);
+  cplx v[8];
+  stft_p1(pw, ww, v, buf, j);
   __syncthreads();
   stft_p2_load(v, buf, j);
   stft_p2_rest(v, buf, T, j);
@@ -347,7 +440,7 @@ __device__ __forceinline__ void stft_frame(cplx (&v)[8], cplx* lds, int j, doubl
   // thread 0's butterflies pair differently: the selects that say so cost 36 instructions per frame
   // (a wave-uniform branch around this call alone was tried: everything live in the frame crosses the split, 76 spilled
   // registers against 16 -- the kernel branches once, outside the frame loop, instead)
-  stft_p4_rest<SPECIAL>(v, T, j, scale, before_out, out);
+  stft_p4_rest<SPECIAL>(v, T, j, before_out, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -494,7 +587,11 @@ __global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   // the loads sit at the head of the frame's dependency chain.)
   double2 ww[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) ww[t] = *reinterpret_cast<const double2*>(a.window + 2 * (j + 256 * t));
+  for (int t = 0; t < 8; ++t) {
+    ww[t] = *reinterpret_cast<const double2*>(a.window + 2 * (j + 256 * t));
+    ww[t].x *= a.wscale;   // (once per workgroup: the scale of the power rides on the window, stft_p4_rest)
+    ww[t].y *= a.wscale;
+  }
 
   // The loads of frame g + gridDim are issued BEFORE frame g's output stores: vmcnt retires in
   // order, so loads issued behind the stores would wait for the stores' HBM acknowledgements.
@@ -536,13 +633,9 @@ __global__ __launch_bounds__(256, STFT_OCC) void stft_psd_kernel(stft_args a) {
   auto frames = [&](auto special_c) {
     constexpr bool SPECIAL = decltype(special_c)::value;
     for (uint32_t g = g0; g < gend; g += gstep) {
-      cplx v[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        v[t] = make_double2((double)(short)(pw[t] & 0xFFFF) * ww[t].x, (double)(pw[t] >> 16) * ww[t].y);
       T* orow = reinterpret_cast<T*>(a.out) + (uint64_t)g * STRIDE;
       stft_frame<SPECIAL>(
-          v, lds, j, a.scale, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
+          pw, ww, lds, j, [&] { if (g + gstep < gend) issue_loads(g + gstep); /* in flight across the stores */ },
           [&](int k, double p) { orow[k] = stage_value<T>(p); });
     }
   };
@@ -1347,6 +1440,7 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.hop = ctx->hop;
   a.tw = ctx->d_twiddle;
   a.scale = 0.25 / ((double)fs * ctx->win_sumsq);
+  a.wscale = sqrt(2.0 * a.scale);
   a.np_window = ctx->d_np_window;
   a.np_comp = (const cplx*)ctx->d_np_comp;
   a.r_fs = 1.0 / (double)fs;          // numpy divides a complex array by a real: it multiplies by the rounded reciprocal
