@@ -166,6 +166,9 @@ __device__ __forceinline__ void dft8f_tail(cplx b0, cplx b1, cplx b2, cplx b3, c
 #ifndef STFT_FUSED
 #define STFT_FUSED 1
 #endif
+#ifndef STFT_TW3_DERIVE
+#define STFT_TW3_DERIVE 0   // 1: four of pass 3's seven twiddles as products of the other three (4 LDS reads less, 16 operations more): 3.806 -> 3.827 ms, off
+#endif
 __device__ __forceinline__ void cmul_pm(cplx a, cplx w, cplx b, cplx& r, cplx& s) {   // r = a + w b, s = a - w b
 #if STFT_FUSED
   r = make_double2(fma(-w.y, b.y, fma(w.x, b.x, a.x)), fma(w.y, b.x, fma(w.x, b.y, a.y)));
@@ -352,8 +355,14 @@ __device__ __forceinline__ void stft_p3_rest(cplx (&v)[8], cplx* buf, const stft
   const int q0 = b3, q1 = (b3 ^ (9 << 4)) + (32 << 4), q2 = (b3 ^ (4 << 4)) + (64 << 4), q3 = (b3 ^ (13 << 4)) + (96 << 4);
   const int k = j & 63;
   cplx w[7];
+#if STFT_TW3_DERIVE
+  // three of the seven twiddles from the table, the others as their products (four LDS reads less, sixteen operations more)
+  w[0] = T.tw3[k]; w[1] = T.tw3[64 + k]; w[3] = T.tw3[3 * 64 + k];
+  w[2] = cmul(w[0], w[1]); w[4] = cmul(w[0], w[3]); w[5] = cmul(w[1], w[3]); w[6] = cmul(w[2], w[3]);
+#else
 #pragma unroll
   for (int t = 1; t < 8; ++t) w[t - 1] = T.tw3[(t - 1) * 64 + k];
+#endif
   dft8f_tw(v, w);
 #pragma unroll
   for (int r = 0; r < 8; ++r) lds_at(buf, ((r & 3) == 0 ? q0 : (r & 3) == 1 ? q1 : (r & 3) == 2 ? q2 : q3) + (r >> 2) * (128 << 4)) = v[r];
