@@ -205,6 +205,11 @@ int32_t shz_set_overlap(shz_ctx* ctx, uint32_t noverlap);
  * sincos_2pibyn(nfft) holds (cos, +sin of 2 pi i / nfft: the forward passes conjugate), *sumsq = (window ** 2).sum() in
  * numpy's pairwise order.  For tests: tests/test_numpy_tables.py compares them with numpy's own bits on the host. */
 int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double* sumsq);
+/* The window of the fp64 path as the host's numpy forms it: window[4096] = np.hanning(4096), sumsq = (window ** 2).sum()
+ * (mlab.window_hanning and the scaling of mlab._spectral_helper behind __init__.py:232-237).  The Python layer calls this for
+ * every context it creates, so the window is numpy's by construction; without the call the libm form of shz_numpy_tables is
+ * used (equal to numpy's on the hosts seen).  Affects the fp64 path only (ties, shz_stft_db), not the fp32 staging kernel. */
+int32_t shz_set_numpy_window(shz_ctx* ctx, const double* window, double sumsq);
 /* mlab.specgram(x, NFFT=nfft, Fs, window_hanning, noverlap)[0] -> 10*log10 where != 0 (__init__.py:232-241) for window sizes
  * OTHER than 4096: nfft a power of two in [64, 2048].  A generic kernel (one workgroup per frame, radix-2 in fp64) -- correct,
  * not fast; the reference and every caller of it use 4096.  pcm: host, one channel; out_db: host [nfft/2 + 1][n_frames]

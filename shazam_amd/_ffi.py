@@ -52,6 +52,7 @@ SIGNATURES = {
     "shz_frame_count_hop": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "shz_set_overlap": (C.c_int32, [vp, C.c_uint32]),
     "shz_numpy_tables": (C.c_int32, [C.c_uint32, vp, vp, vp]),
+    "shz_set_numpy_window": (C.c_int32, [vp, vp, C.c_double]),
     "shz_stft_db_any": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
@@ -194,6 +195,10 @@ class Context:
             raise ShzError(rc, f"shz_ctx_create(device {device_id}) failed -- is a ROCm GPU visible?")
         self.h = h
         self.device_id = device_id
+        # the fp64 path's window as THIS host's numpy forms it (mlab.window_hanning = np.hanning; the scaling by
+        # (window ** 2).sum()): numpy's by construction, not by the agreement of two cosine routines
+        w = np.hanning(4096)
+        self.check(lib().shz_set_numpy_window(self.h, ptr(w), float((w ** 2).sum())))
 
     def check(self, rc):
         if rc != OK:

@@ -233,6 +233,30 @@ void shz_numpy_tables_host(uint32_t n, double* window, double2* comp, double* su
   }
 }
 
+// the window of the fp64 path as THE HOST'S numpy forms it (np.hanning(4096) and (window ** 2).sum()): the Python layer hands
+// both over when it creates a context, so that the window is numpy's by construction and not by the agreement of two cosine
+// routines (numpy may use a vendor routine where this library uses libm; on the hosts seen so far they agree on all 4,096
+// arguments).  A C caller that sets nothing gets the libm form of shz_numpy_tables.
+extern "C" int32_t shz_set_numpy_window(shz_ctx* ctx, const double* window, double sumsq) {
+  if (!ctx) return SHZ_E_INVALID;
+  if (!window) SHZ_FAIL(ctx, SHZ_E_INVALID, "window is NULL");
+  // (tested on the bits: this file is compiled with -fno-honor-nans)
+  auto finite_below = [](double v, double lim) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return ((b >> 52) & 0x7FFu) != 0x7FFu && (b & 0x7FFFFFFFFFFFFFFFull) <= [&] { uint64_t l; memcpy(&l, &lim, 8); return l; }();
+  };
+  if (!finite_below(sumsq, 1e300) || !(sumsq > 0.0)) SHZ_FAIL(ctx, SHZ_E_INVALID, "sum of the squared window must be positive and finite");
+  for (int i = 0; i < SHZ_NFFT; ++i)
+    if (!finite_below(window[i], 2.0)) SHZ_FAIL(ctx, SHZ_E_INVALID, "window[%d] is not a window value", i);
+  SHZ_HIP(ctx, hipSetDevice(ctx->device));
+  SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SHZ_HIP(ctx, hipMemcpy(ctx->d_np_window, window, sizeof(double) * SHZ_NFFT, hipMemcpyHostToDevice));
+  ctx->np_sumsq = sumsq;
+  if (ctx->twin) return shz_set_numpy_window(ctx->twin, window, sumsq);
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double* sumsq) {
   if (nfft < 2 || nfft > (1u << 20)) return SHZ_E_INVALID;
   shz_numpy_tables_host(nfft, window, (double2*)twiddles, sumsq);

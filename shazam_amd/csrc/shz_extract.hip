@@ -2387,10 +2387,14 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
     if (!ctx->twin) {
       SHZ_TRY(shz_ctx_create(ctx->device, &ctx->twin));
       SHZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+      // the caller's numpy window (shz_set_numpy_window) goes with it
+      SHZ_HIP(ctx, hipMemcpy(ctx->twin->d_np_window, ctx->d_np_window, sizeof(double) * SHZ_NFFT, hipMemcpyDeviceToDevice));
+      ctx->twin->np_sumsq = ctx->np_sumsq;
     }
     shz_ctx* tw = ctx->twin;
     tw->ws_limit = ctx->ws_limit;
     tw->profiling = ctx->profiling;
+    tw->hop = ctx->hop;
     // the twin starts behind everything queued on this context's stream (the caller's PCM may still be in the making)
     SHZ_HIP(ctx, hipEventRecord(ctx->ev_twin, ctx->stream));
     SHZ_HIP(ctx, hipStreamWaitEvent(tw->stream, ctx->ev_twin, 0));

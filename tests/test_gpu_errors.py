@@ -176,6 +176,13 @@ def test_round4_entry_points_refuse_bad_arguments(env):
     assert nf.value == 18
     assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, None, 0, C.byref(nf)) == _ffi.E_CAPACITY
     assert L.shz_stft_db_any(ctx.h, _ffi.ptr(xs), 5000, 44100, 512, 256, 0, _ffi.ptr(out), out.size, None) == _ffi.OK
+    # the numpy window of the fp64 path: NULL, a sum that is no sum, values that are no window -- and the right one again
+    w = np.hanning(4096)
+    assert L.shz_set_numpy_window(None, _ffi.ptr(w), 1535.625) == _ffi.E_INVALID
+    assert L.shz_set_numpy_window(ctx.h, None, 1535.625) == _ffi.E_INVALID
+    assert L.shz_set_numpy_window(ctx.h, _ffi.ptr(w), 0.0) == _ffi.E_INVALID
+    assert L.shz_set_numpy_window(ctx.h, _ffi.ptr(np.full(4096, np.nan)), 1535.625) == _ffi.E_INVALID
+    assert L.shz_set_numpy_window(ctx.h, _ffi.ptr(w), float((w ** 2).sum())) == _ffi.OK
     # run rows: 0 (the limit of a sort) or >= 16
     tbl = S.Table(ctx)
     assert L.shz_table_set_run_rows(tbl.h, 5) == _ffi.E_INVALID and L.shz_table_set_run_rows(tbl.h, 0) == _ffi.OK
