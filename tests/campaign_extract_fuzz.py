@@ -1,13 +1,13 @@
 """Randomised campaign for the extraction pass (not part of the suite): the default path (fp32 staging, ties handed to the
 reference's arithmetic) against fp64 staging of everything (numpy's arithmetic throughout) -- peaks, hashes and offsets must be
 the same arrays.  Inputs lean towards what makes ties: tones, clicks, tiny amplitudes (a few counts: many equal powers),
-repeated material, clipping, silence, DC, mixtures.   python scripts/extract_fuzz.py [seconds] [seed0]"""
+repeated material, clipping, silence, DC, mixtures.   python tests/campaign_extract_fuzz.py [seconds] [seed0]"""
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # (run from the repo root; lives under tests/ because it draws its inputs from the oracle's generators)
 import shazam_amd as S  # noqa: E402
 from oracle import synth  # noqa: E402
 
