@@ -10,7 +10,7 @@ $B --songs 100000 --queries 4000 --snr 10 > $O/${TAG}_bench_db_100k_snr10.json
 $B --songs 100000 --queries 4000 --snr 0 > $O/${TAG}_bench_db_100k_snr0.json
 $B --songs 100000 --queries 4000 --snr 10 --shards 4 > $O/${TAG}_bench_db_100k_snr10_shards4.json
 $B --songs 100000 --queries 2000 --snr 10 --match-batch 200 --mixed-ingest 1000 > $O/${TAG}_bench_db_mixed_100k.json
-$B --songs 1000000 --queries 2000 --query-seconds 10 --snr 10 --match-batch 200 --finalize-every 100000 --mixed-ingest 1000 > $O/${TAG}_bench_db_config5_mixed_1M.json
+$B --songs 1000000 --queries 2000 --query-seconds 10 --snr 10 --match-batch 200 --finalize-every 50000 --mixed-ingest 1000 > $O/${TAG}_bench_db_config5_mixed_1M.json
 for f in $O/${TAG}_bench_db_*.json; do echo $f; python - $f <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

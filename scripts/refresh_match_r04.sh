@@ -6,7 +6,6 @@ TAG=${1:-r04}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
-sed -i 's/--finalize-every 100000 --mixed-ingest/--finalize-every 50000 --mixed-ingest/' scripts/refresh_bench_db.sh
 bash scripts/refresh_bench_db.sh $TAG > $O/${TAG}_bench_db.log 2>&1
 echo "bench_db done"; tail -14 $O/${TAG}_bench_db.log
 cd /tmp && export TMPDIR=/tmp

@@ -1831,7 +1831,11 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     // (the lowest ids: their bars are the ones that bind everybody else) decide on the spot; the others note an undecided
     // batch -- its range, first ordered bits and largest counter, in the registers of lane i for note i -- and decide
     // when the tile's stream has ended (or 64 notes are there), in order, against the bar of that moment.
-    const bool seed_tile = g - pl.tb[qi] < VW_SEED_TILES;
+    // (a sixteenth of the query's tiles, between 4 and VW_SEED_TILES: 100k songs, ~110 tiles a query: 9.95 us a query with 64
+    // seeds -- nearly every tile folding on the spot --, 9.25 with 8; 1M songs, 1,100-4,400 tiles: 4 / 16 / 64 within 2 %)
+    const uint32_t q_tiles = pl.tb[qi + 1] - pl.tb[qi];
+    const uint32_t n_seed = min(max(q_tiles >> 4, 4u), VW_SEED_TILES);
+    const bool seed_tile = g - pl.tb[qi] < n_seed;
     uint32_t npend = 0;                              // wave-uniform
     uint32_t pd_s = 0, pd_e = 0, pd_hi = 0, pd_c = 0;   // lane i: note i
     auto run_pending = [&]() {
@@ -2113,12 +2117,14 @@ static void vt_make_plan(const uint64_t* counts, uint32_t nqp, const m_bits& mbp
   pl.g_lo = std::max(1 + mbp.dbits, Bt - VT_ORDERED_BITS);
   // votes per tile: a tile pays a fixed price (its place in the plan, the query's bar, the first loads' latency, its
   // candidates' way through vt_rank_kernel) that 2,048 votes do not amortise -- 1M songs, batches of 200: 0.147 ms a query at
-  // 2,048, 0.141 at 4,096, 0.138 at 8,192, 0.136 at 16,384 -- but the chip wants ~2 rounds of tiles (256 CUs x 26 waves)
+  // 2,048, 0.141 at 4,096, 0.138 at 8,192, 0.136 at 16,384 -- but the chip wants ~2 rounds of tiles (256 CUs x 26 waves).
+  // (Those were the fold of mid round 4; with deferred batches and batches of 128: 0.1365 at 2,048, 0.1348 at 4,096, 0.132 at
+  // 8,192, 0.1348 at 16,384, 0.1418 at 32,768: the cap is 8,192.)
   static const uint32_t chunk_env = [] { const char* e = getenv("SHZ_VW_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1024 && v <= 65536 ? (uint32_t)v : 0u; }();
   uint64_t all_votes = 0;
   for (uint32_t i = 0; i < nqp; ++i) all_votes += counts[i];
   uint32_t chunk = VW_CHUNK;
-  while (chunk < 16384u && all_votes / (2ull * chunk) >= 13312ull) chunk *= 2;
+  while (chunk < 8192u && all_votes / (2ull * chunk) >= 13312ull) chunk *= 2;
   // (one query of 8.9 M votes, fewer tiles than wave slots: 1,024 votes a tile 0.379 ms, 2,048: 0.354, 4,096: 0.349 -- smaller tiles
   // do not shorten the pass, every tile pays its start)
   if (chunk_env) chunk = chunk_env;
