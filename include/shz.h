@@ -210,6 +210,10 @@ int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double
  * every context it creates, so the window is numpy's by construction; without the call the libm form of shz_numpy_tables is
  * used (equal to numpy's on the hosts seen).  Affects the fp64 path only (ties, shz_stft_db), not the fp32 staging kernel. */
 int32_t shz_set_numpy_window(shz_ctx* ctx, const double* window, double sumsq);
+/* How the host's numpy multiplies complex numbers (`np.conj(result) * result` in mlab._spectral_helper): fused = 1 (default):
+ * real part fma(re, re, im * im) -- numpy's SIMD product on x86-64 with FMA3, the hosts of the fixtures; fused = 0:
+ * re * re + im * im.  The Python layer probes its numpy when it creates a context and says which. */
+int32_t shz_set_numpy_product(shz_ctx* ctx, int32_t fused);
 /* mlab.specgram(x, NFFT=nfft, Fs, window_hanning, noverlap)[0] -> 10*log10 where != 0 (__init__.py:232-241) for window sizes
  * OTHER than 4096: nfft a power of two in [64, 2048].  A generic kernel (one workgroup per frame, radix-2 in fp64) -- correct,
  * not fast; the reference and every caller of it use 4096.  pcm: host, one channel; out_db: host [nfft/2 + 1][n_frames]

@@ -190,8 +190,9 @@ def fft_pow8(x):
     return fft_pow2(x)
 
 
-def psd_exact(x, Fs=44100, noverlap=2048, nfft=4096) -> np.ndarray:
-    """mlab.specgram(x, NFFT=4096, Fs, window_hanning, noverlap)[0], float64 [2049][F]."""
+def psd_exact(x, Fs=44100, noverlap=2048, nfft=4096, fused=True) -> np.ndarray:
+    """mlab.specgram(x, NFFT=nfft, Fs, window_hanning, noverlap)[0], float64 [nfft/2 + 1][F].  fused: numpy's complex product
+    has FMA3 on the host (the fixtures' hosts); False: re*re + im*im."""
     x = np.asarray(x)
     if len(x) < nfft:
         xp = np.zeros(nfft, x.dtype if x.size else np.int16)
@@ -204,7 +205,7 @@ def psd_exact(x, Fs=44100, noverlap=2048, nfft=4096) -> np.ndarray:
     for f, fr in enumerate(frames):
         z = fft_pow2(fr * w)[: nfft // 2 + 1]
         re, im = z.real.copy(), z.imag.copy()
-        p = _fma(re, re, im * im).astype(np.float64)
+        p = _fma(re, re, im * im).astype(np.float64) if fused else re * re + im * im
         p[1:-1] *= 2.0
         out[:, f] = (p * r_fs) * r_s
     return out

@@ -53,6 +53,7 @@ SIGNATURES = {
     "shz_set_overlap": (C.c_int32, [vp, C.c_uint32]),
     "shz_numpy_tables": (C.c_int32, [C.c_uint32, vp, vp, vp]),
     "shz_set_numpy_window": (C.c_int32, [vp, vp, C.c_double]),
+    "shz_set_numpy_product": (C.c_int32, [vp, C.c_int32]),
     "shz_stft_db_any": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_stft_db": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
     "shz_db_values": (C.c_int32, [vp, C.c_uint64, vp]),
@@ -114,6 +115,31 @@ SIGNATURES = {
     "shz_pairs_vote": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    vp, vp, vp, vp, vp]),
 }
+
+
+_NP_FUSED = None
+
+
+def numpy_product_is_fused() -> bool:
+    """Does this host's numpy form the real part of conj(z) * z as fma(re, re, im * im)?  (mlab's `np.conj(result) * result`;
+    numpy's SIMD complex product uses FMA3 where the CPU has it.)  Probed once on values for which the two roundings differ;
+    an inconclusive probe means fused, the form of the hosts that made the fixtures."""
+    global _NP_FUSED
+    if _NP_FUSED is None:
+        import fractions
+        rng = np.random.default_rng(12345)
+        z = (rng.standard_normal(64) + 1j * rng.standard_normal(64)) * 1e3
+        got = (np.conj(z) * z).real
+        votes = []
+        for v, g in zip(z, got):
+            re, im = float(v.real), float(v.imag)
+            plain = re * re + im * im
+            exact = fractions.Fraction(re) * fractions.Fraction(re) + fractions.Fraction(im * im)   # what an FMA rounds
+            fused = float(exact)                                                                   # (Fraction -> float rounds to nearest even)
+            if plain != fused:
+                votes.append(g == fused)
+        _NP_FUSED = bool(sum(votes) * 2 >= len(votes)) if votes else True
+    return _NP_FUSED
 
 
 class ShzError(RuntimeError):
@@ -199,6 +225,7 @@ class Context:
         # (window ** 2).sum()): numpy's by construction, not by the agreement of two cosine routines
         w = np.hanning(4096)
         self.check(lib().shz_set_numpy_window(self.h, ptr(w), float((w ** 2).sum())))
+        self.check(lib().shz_set_numpy_product(self.h, 1 if numpy_product_is_fused() else 0))
 
     def check(self, rc):
         if rc != OK:
@@ -413,6 +440,10 @@ class Context:
             res.append(out[pos:pos + f * NBINS].reshape(NBINS, f))
             pos += f * NBINS
         return res
+
+    def set_numpy_product(self, fused: bool):
+        """How the host's numpy forms conj(z) * z (see numpy_product_is_fused); set by __init__ from a probe."""
+        self.check(lib().shz_set_numpy_product(self.h, 1 if fused else 0))
 
     def stft_db_any(self, x, fs=44100, nfft=2048, noverlap=1024, power=False) -> np.ndarray:
         """dB spectrogram [nfft/2 + 1, frames] of one channel for a window size other than 4096 (generic kernel)."""

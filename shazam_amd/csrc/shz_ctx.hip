@@ -257,6 +257,16 @@ extern "C" int32_t shz_set_numpy_window(shz_ctx* ctx, const double* window, doub
   return SHZ_OK;
 }
 
+// how the host's numpy multiplies complex numbers: `np.conj(result) * result` of mlab._spectral_helper yields
+// fma(re, re, im * im) where numpy's SIMD product has FMA3 (x86-64 AVX2 / AVX-512, the hosts of the fixtures), re*re + im*im
+// where it has not.  The Python layer probes its numpy and says which (fused = 1 is the default).
+extern "C" int32_t shz_set_numpy_product(shz_ctx* ctx, int32_t fused) {
+  if (!ctx) return SHZ_E_INVALID;
+  ctx->np_unfused = fused == 0;
+  if (ctx->twin) ctx->twin->np_unfused = ctx->np_unfused;
+  return SHZ_OK;
+}
+
 extern "C" int32_t shz_numpy_tables(uint32_t nfft, double* window, double* twiddles, double* sumsq) {
   if (nfft < 2 || nfft > (1u << 20)) return SHZ_E_INVALID;
   shz_numpy_tables_host(nfft, window, (double2*)twiddles, sumsq);

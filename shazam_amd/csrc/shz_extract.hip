@@ -87,6 +87,7 @@ struct stft_args {
   const double* np_window;
   const cplx* np_comp;
   double r_fs, r_s;
+  uint32_t np_unfused;         // 1: numpy's complex product without FMA (re*re + im*im): a host whose numpy has no FMA3 (shz_set_numpy_product)
 };
 
 // The staged spectrogram holds POWER, not dB.  10*log10 is non-decreasing, so the window maximum of the dB values
@@ -527,8 +528,8 @@ __device__ __forceinline__ void np_fft4096(cplx* buf, const cplx* __restrict__ t
   }
 }
 // power of bin k from its transform value, scaled as mlab scales it
-__device__ __forceinline__ double np_power(cplx X, int k, double r_fs, double r_s) {
-  double p = fma(X.x, X.x, X.y * X.y);
+__device__ __forceinline__ double np_power(cplx X, int k, double r_fs, double r_s, uint32_t unfused = 0) {
+  double p = unfused ? X.x * X.x + X.y * X.y : fma(X.x, X.x, X.y * X.y);
   if (k != 0 && k != SHZ_NFFT / 2) p *= 2.0;
   p = p * r_fs;
   return p * r_s;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void stft_np_kernel(stft_args a) {
 #pragma unroll
     for (int t = 0; t <= 8; ++t) {
       const int k = j + 256 * t;
-      if (k <= SHZ_NFFT / 2) orow[k] = stage_value<double>(np_power(buf[k], k, a.r_fs, a.r_s));
+      if (k <= SHZ_NFFT / 2) orow[k] = stage_value<double>(np_power(buf[k], k, a.r_fs, a.r_s, a.np_unfused));
     }
     __syncthreads();   // buf is rewritten by the next frame
   }
@@ -1454,6 +1455,7 @@ static stft_args make_stft_args(shz_ctx* ctx, const int16_t* d_pcm, const sub_de
   a.np_comp = (const cplx*)ctx->d_np_comp;
   a.r_fs = 1.0 / (double)fs;          // numpy divides a complex array by a real: it multiplies by the rounded reciprocal
   a.r_s = 1.0 / ctx->np_sumsq;
+  a.np_unfused = ctx->np_unfused ? 1u : 0u;
   a.frames_per_wg = 0;
   static const uint32_t opt_env = [] { const char* e = getenv("SHZ_STFT_OPT"); return e ? (uint32_t)atoi(e) : 0u; }();
   a.opt = opt_env;
@@ -1667,7 +1669,8 @@ struct any_plan {
 
 __global__ __launch_bounds__(256) void stft_any_kernel(const int16_t* __restrict__ pcm, uint64_t n, uint32_t nfft, uint32_t hop,
                                                        uint32_t F, const double* __restrict__ window, const cplx* __restrict__ tw,
-                                                       any_plan pl, double r_fs, double r_s, int as_power, double* __restrict__ out) {
+                                                       any_plan pl, double r_fs, double r_s, int as_power, uint32_t unfused,
+                                                       double* __restrict__ out) {
   extern __shared__ cplx gs_lds[];
   cplx* a = gs_lds;
   cplx* b = gs_lds + nfft;
@@ -1715,7 +1718,7 @@ __global__ __launch_bounds__(256) void stft_any_kernel(const int16_t* __restrict
   }
   for (uint32_t k = tid; k <= half; k += 256) {
     const cplx X = a[k];
-    double p = fma(X.x, X.x, X.y * X.y);
+    double p = unfused ? X.x * X.x + X.y * X.y : fma(X.x, X.x, X.y * X.y);
     if (k != 0 && k != half) p *= 2.0;
     p = p * r_fs;
     p = p * r_s;
@@ -1776,7 +1779,7 @@ extern "C" int32_t shz_stft_db_any(shz_ctx* ctx, const int16_t* pcm, uint64_t n_
   // P * 2 (bins 1 .. N/2 - 1), / Fs, / sum(w^2) as numpy does them: the divisions are products with the rounded reciprocals
   hipLaunchKernelGGL(stft_any_kernel, dim3(F), dim3(256), (size_t)nfft * 2 * sizeof(cplx), ctx->stream, (const int16_t*)d_pcm, n_samples,
                      nfft, hop, F, (const double*)d_win, (const cplx*)d_tw, pl, 1.0 / (double)fs, 1.0 / sumsq,
-                     (flags & SHZ_STFT_POWER) ? 1 : 0, (double*)d_out);
+                     (flags & SHZ_STFT_POWER) ? 1 : 0, ctx->np_unfused ? 1u : 0u, (double*)d_out);
   SHZ_HIP(ctx, hipGetLastError());
   SHZ_HIP(ctx, shz_memcpy(ctx, out_db, d_out, (uint64_t)F * bins * 8, hipMemcpyDeviceToHost));
   SHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2390,6 +2393,7 @@ static int32_t extract_driver(shz_ctx* ctx, const int16_t* pcm, const uint64_t* 
       // the caller's numpy window (shz_set_numpy_window) goes with it
       SHZ_HIP(ctx, hipMemcpy(ctx->twin->d_np_window, ctx->d_np_window, sizeof(double) * SHZ_NFFT, hipMemcpyDeviceToDevice));
       ctx->twin->np_sumsq = ctx->np_sumsq;
+      ctx->twin->np_unfused = ctx->np_unfused;
     }
     shz_ctx* tw = ctx->twin;
     tw->ws_limit = ctx->ws_limit;

@@ -104,6 +104,7 @@ struct shz_ctx {
   double* d_np_window = nullptr;
   double2* d_np_comp = nullptr;
   double np_sumsq = 0.0;
+  bool np_unfused = false;       // numpy's complex product on this host has no FMA (shz_set_numpy_product)
   uint32_t hop = SHZ_HOP;          // new samples per frame: NFFT - noverlap (shz_set_overlap; the reference's wratio)
   // timers / profiling
   hipEvent_t tev[16][2];

@@ -48,3 +48,25 @@ def test_batch_members_and_oracle(golden_dir):
         assert np.array_equal(P, alone)
         want = E.psd_exact(x, 44100, 2048)
         assert np.array_equal(P, np.where(want == 0, 1.0, want))
+
+
+def test_unfused_product_variant(golden_dir):
+    """A host whose numpy has no FMA3 forms re*re + im*im: the library follows (shz_set_numpy_product), the oracle says what
+    that gives, and it is NOT the fixtures' digest."""
+    import shazam_amd as S
+    from oracle import np_exact as E
+    ctx = S.get_context(0)
+    x, d = psd_cases(golden_dir)["variant_wr0"]
+    ctx.set_numpy_product(False)
+    try:
+        P = _power(ctx, x, 0.0, 44100)
+        P512 = _power(ctx, x[:20000], 0.5, 44100, 512)
+    finally:
+        ctx.set_numpy_product(True)
+    want = E.psd_exact(x, 44100, 0, 4096, fused=False)
+    assert np.array_equal(P, np.where(want == 0, 1.0, want))
+    assert hashlib.sha256(np.ascontiguousarray(P).tobytes()).hexdigest() != d["sha256"]
+    want = E.psd_exact(x[:20000], 44100, 256, 512, fused=False)
+    assert np.array_equal(P512, np.where(want == 0, 1.0, want))
+    assert hashlib.sha256(np.ascontiguousarray(_power(ctx, x, 0.0, 44100)).tobytes()).hexdigest() == d["sha256"]
+

@@ -71,3 +71,11 @@ def test_oracle_spectrogram_hits_the_references_digest(golden_dir, name):
     for a, b, v in d["probe"]:
         assert float(np.where(P == 0, 1.0, P)[a, b]).hex() == v
     assert _digest(P) == d["sha256"]
+
+
+def test_this_hosts_numpy_product_is_what_the_fixtures_hosts_was():
+    """The digests were made on a host whose numpy multiplies complex numbers with FMA3; the probe the Python layer runs for
+    every context must say so here (the oracle hits the digests with fused=True above, and misses with fused=False)."""
+    from shazam_amd import _ffi
+    assert _ffi.numpy_product_is_fused() is True
+
