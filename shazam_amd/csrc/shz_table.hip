@@ -1848,26 +1848,24 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
       }
       npend = 0;
     };
-    auto end_batch = [&](uint32_t e, uint32_t next_hi) {   // next_hi: the ordered bits of the vote at e (the next batch's first)
+    // ONE place ends a batch (the row loop below) and ONE place folds exactly (run_pending): the exact fold is a long piece
+    // of code -- probe loops, the top-n merge -- and the seven inlined copies it had made a 16,000-instruction kernel.
+    auto end_batch = [&](uint32_t e, uint32_t next_hi, bool last) {   // next_hi: the ordered bits of the vote at e (the next batch's first)
       ++st_b;
-      bool fold_now = false;
+      bool noted = false;
       if (hit != 0ull || thr1 < 2u) {                // a counter reached the batch's threshold, or songs of count 1 may still enter
         const uint32_t w = vt_wave_max(cm), cmax = w < 1u ? 1u : w;
-        if (seed_tile) {
-          if (hit != 0ull) refresh_bar();            // (it has risen since the batch began, more often than not)
-          fold_now = needed(cmax, cur_hi);
-        } else {
-          ++st_seed;
-          if (npend == 64u) { clear_filter(); run_pending(); }
-          if (lane == npend) { pd_s = batch_start; pd_e = e; pd_hi = cur_hi; pd_c = cmax; }
-          ++npend;
-          // a tile that keeps noting batches has a stale bar (none, if it started with its query): look again now and then
-          // -- with a bar worth having, notes become rare and so do these loads
-          if ((npend & 7u) == 0u) refresh_bar();
-        }
+        ++st_seed;
+        if (lane == npend) { pd_s = batch_start; pd_e = e; pd_hi = cur_hi; pd_c = cmax; }
+        ++npend;
+        noted = true;
       }
-      if (fold_now) { ++st_beat; st_votes_redo += e - batch_start; exact_batch(batch_start, e); }
-      else clear_filter();
+      clear_filter();
+      // decide now: a seed tile's note (on the spot), 64 notes, the end of the tile.  Otherwise a tile that keeps noting batches
+      // has a stale bar (none, if it started with its query): it looks again now and then -- with a bar worth having, notes
+      // become rare and so do these loads
+      if (npend != 0u && (seed_tile || npend == 64u || last)) run_pending();
+      else if (noted && (npend & 7u) == 0u) refresh_bar();
       set_thr(next_hi);
       hit = 0ull;
       cm = 0;
@@ -1903,49 +1901,57 @@ __global__ __launch_bounds__(64) void vt_stream2_kernel(const uint32_t* __restri
     uint32_t rr[VW_AHEAD];
 #pragma unroll
     for (int j = 0; j < VW_AHEAD; ++j) { const uint32_t i = a + lane + 64u * j; rr[j] = i < b ? k[i] : 0u; }
-    for (uint32_t base = a; base < b; base += 64) {
-      const uint32_t v = rr[0];
+    for (uint32_t base = a;; base += 64) {
+      // behind the last vote comes a pseudo-row with a border at lane 0: it ends the last batch where every batch ends
+      const bool tail = base >= b;
+      uint32_t v = 0, hi = 0;
+      unsigned long long mg = 1ull;
+      bool valid = false;
+      if (!tail) {
+        v = rr[0];
 #pragma unroll
-      for (int j = 0; j + 1 < VW_AHEAD; ++j) rr[j] = rr[j + 1];
-      { const uint32_t i = base + 64u * VW_AHEAD + lane; rr[VW_AHEAD - 1] = i < b ? k[i] : 0u; }
-      const bool valid = base + lane < b;
-      const uint32_t hi = v >> pl.g_lo;
-      const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)last_hi, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      const unsigned long long mg = __ballot(valid && hi != hp);     // lanes that open a group
-      last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);    // (the last row is the only partial one)
-      if (base == a) set_thr((uint32_t)__builtin_amdgcn_readfirstlane((int)hi));
-      if (mg == 0ull || batch_votes < pl.flush) {                    // no border in the row, or none that may end the batch (it is
-        // still below its flush size when the row begins: the whole row joins it, as in vt_stream_kernel): one piece
-        if (base + 64u <= b) {                                       // a whole row: issued now, looked at with the next row
-          const uint32_t h = vw_hash_filter(v >> 1), sh = (h & 3u) << 3;
-          const uint32_t old = atomicAdd(&filt[h >> 2], 1u << sh);
-          consume();
-          p_old = old; p_sh = sh; p_any = true;
-          batch_votes += 64u;
-        } else {
-          consume();
-          fast_insert(valid, v);
-          batch_votes += b - base;
+        for (int j = 0; j + 1 < VW_AHEAD; ++j) rr[j] = rr[j + 1];
+        { const uint32_t i = base + 64u * VW_AHEAD + lane; rr[VW_AHEAD - 1] = i < b ? k[i] : 0u; }
+        valid = base + lane < b;
+        hi = v >> pl.g_lo;
+        const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)last_hi, (int)hi, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        mg = __ballot(valid && hi != hp);                            // lanes that open a group
+        last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);  // (the last row is the only partial one)
+        if (base == a) set_thr((uint32_t)__builtin_amdgcn_readfirstlane((int)hi));
+        if (mg == 0ull || batch_votes < pl.flush) {                  // no border in the row, or none that may end the batch (it is
+          // still below its flush size when the row begins: the whole row joins it, as in vt_stream_kernel): one piece
+          if (base + 64u <= b) {                                     // a whole row: issued now, looked at with the next row
+            const uint32_t h = vw_hash_filter(v >> 1), sh = (h & 3u) << 3;
+            const uint32_t old = atomicAdd(&filt[h >> 2], 1u << sh);
+            consume();
+            p_old = old; p_sh = sh; p_any = true;
+            batch_votes += 64u;
+          } else {
+            consume();
+            fast_insert(valid, v);
+            batch_votes += b - base;
+          }
+          continue;
         }
-        continue;
       }
       consume();
       uint32_t lo = 0;                               // first lane of the row not dealt with yet
       while (lo < 64) {                              // uniform
         const unsigned long long rest = mg & ~((1ull << lo) - 1ull);
         uint32_t cut = 64;                           // the batch may end at the next group border once it is large enough
-        if (batch_votes >= pl.flush && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
-        if (cut == lo) { end_batch(base + lo, (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)lo)); continue; }
+        if ((batch_votes >= pl.flush || tail) && rest) cut = (uint32_t)__ffsll((long long)rest) - 1;
+        if (cut == lo) {
+          end_batch(tail ? b : base + lo, tail ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)lo), tail);
+          if (tail) break;
+          continue;
+        }
         const bool act = valid && lane >= lo && lane < cut;
         fast_insert(act, v);
         batch_votes += (uint32_t)__popcll(__ballot(act));
-        if (cut < 64) end_batch(base + cut, (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)cut));
-        lo = cut;
+        lo = cut;                                    // (a border at `cut` ends the batch at the top of this loop)
       }
+      if (tail) break;
     }
-    consume();
-    end_batch(b, 0xFFFFFFFFu);
-    run_pending();
     if (stats && lane == 0) {
       atomicAdd(stats + 0, (unsigned long long)st_b);
       atomicAdd(stats + 2, (unsigned long long)st_seed); atomicAdd(stats + 3, (unsigned long long)st_beat);
